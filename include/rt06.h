@@ -1,0 +1,272 @@
+/*
+ * rt06.h — C ABI of the MI355X-native path-tracer hot path.
+ *
+ * This is the drop-in boundary for the per-pixel sample loop of
+ * SuperCat908809/Ray-Tracing-v06.  The reference has no FFI layer; the boundary
+ * the hot path sits behind is its C++ class `Renderer`
+ * (main/src/Renderer.h:38-46) plus the scene vocabulary that produces the
+ * `world` argument.  Each entry point below names the reference interface it
+ * replaces.  The reference-shaped C++ classes in include/rt06/ (Renderer,
+ * SphereHandle, BVH_Handle::Factory, cameras, materials, scenes) are thin
+ * header-only wrappers over exactly these functions.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns an int status
+ *    (0 = RT_OK) and never throws; rt_last_error() returns the message of the
+ *    last failure on the calling thread.  The reference's CUDA_ASSERT is a
+ *    no-op in Release (utilities/cuda_utilities/cuError.h:25-29); this ABI is
+ *    never silent.
+ *  - all floating point is IEEE fp32; vectors are float[3] (x,y,z).
+ *  - the framebuffer is row-major float RGBA, 16 B per pixel, alpha = 1,
+ *    row 0 = BOTTOM row of the image, values sqrt-gamma in [0,1]
+ *    (Renderer.cu:206-216).
+ *  - objects are not thread-safe; distinct objects are independent.
+ */
+#ifndef RT06_H
+#define RT06_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID 1   /* bad argument / malformed scene                */
+#define RT_ERR_HIP 2       /* a HIP runtime call failed                     */
+#define RT_ERR_NO_DEVICE 3 /* no usable gfx950 device                       */
+#define RT_ERR_STACK 4     /* BVH deeper than the traversal stack allows    */
+
+/* ------------------------------------------------------------------ */
+/* GPU-linear scene records (what hittable_list / bvh_node / BVH flatten to) */
+/* ------------------------------------------------------------------ */
+
+/* == BVH::Node, rt_engine/geometry/BVH.cuh:16-25 (32 B, same field order).
+ * RT_WORLD_BVH      : left == -1  -> leaf, right = primitive index;
+ *                     otherwise left/right are child node indices.
+ * RT_WORLD_NODE_TREE: (== bvh_node, rt_engine/geometry/bvh_node.cuh:9-25)
+ *                     left/right are child references: r >= 0 is a node
+ *                     index, r < 0 is primitive index (-r - 1).            */
+typedef struct rt_bvh_node {
+    float   min[3];
+    float   max[3];
+    int32_t left;
+    int32_t right;
+} rt_bvh_node;
+
+#define RT_PRIM_MOVING 0x80000000u
+/* Sphere (SphereHittable.cuh:35-52) / MovingSphere (:70-87) + its material
+ * binding (SphereHittable{sphere*,mat*}, :56-67), 32 B.
+ * mat = material index, bit 31 set for a MovingSphere (c1 is then used).   */
+typedef struct rt_prim {
+    float    c0[3];
+    float    radius;
+    float    c1[3];
+    uint32_t mat;
+} rt_prim;
+
+enum {
+    RT_MAT_LAMBERTIAN = 0,         /* LambertianAbstract  cu_materials.cuh:44-65  param unused          */
+    RT_MAT_METAL = 1,              /* MetalAbstract       cu_materials.cuh:68-96  param = fuzz          */
+    RT_MAT_DIELECTRIC = 2,         /* DielectricAbstract  cu_materials.cuh:106-144 param = ior          */
+    RT_MAT_LAMBERTIAN_CHECKER = 3  /* LambertianTexture   cu_materials.cuh:16-41  albedo/albedo2 = even/odd colour, param = 1/scale */
+};
+typedef struct rt_material {
+    float    albedo[3];
+    float    param;
+    float    albedo2[3];
+    uint32_t type;
+} rt_material;
+
+enum {
+    RT_WORLD_BVH = 0,       /* flat index-linked BVH          (BVH.cu:54-106)           */
+    RT_WORLD_LIST = 1,      /* HittableList                   (HittableList.cuh:21-34)  */
+    RT_WORLD_NODE_TREE = 2  /* pointer-recursive bvh_node     (bvh_node.cuh:19-24)      */
+};
+/* The `const Hittable* d_world_ptr` argument of Renderer::MakeRenderer,
+ * resolved to flat host arrays.  Borrowed during rt_renderer_create only.   */
+typedef struct rt_world_flat {
+    uint32_t kind;         /* RT_WORLD_*                                              */
+    int32_t  root;         /* root node index (BVH: last node; NODE_TREE: child ref)  */
+    uint32_t n_nodes;
+    uint32_t n_prims;
+    uint32_t n_materials;
+    uint32_t max_stack;    /* traversal-stack bound derived from the tree at build time */
+    float    bounds_min[3];/* world bounds (HittableList pre-test, HittableList.cuh:22) */
+    float    bounds_max[3];
+    const rt_bvh_node* nodes;
+    const rt_prim*     prims;
+    const rt_material* materials;
+} rt_world_flat;
+
+enum {
+    RT_CAM_PINHOLE = 0,  /* PinholeCamera     cu_Cameras.cuh:12-31 */
+    RT_CAM_DEFOCUS = 1,  /* DefocusBlurCamera cu_Cameras.cuh:34-65 */
+    RT_CAM_MOTION = 2    /* MotionBlurCamera  cu_Cameras.cuh:68-90 */
+};
+/* Camera POD, passed by value to the kernel like LaunchParams::cam
+ * (Renderer.cu:99-108,117).  For PINHOLE/MOTION u,v are pre-scaled by the
+ * viewport; for DEFOCUS they are unit vectors and viewport_* are separate.  */
+typedef struct rt_camera {
+    uint32_t type;
+    float o[3], u[3], v[3], w[3];
+    float viewport_width, viewport_height;
+    float lens_radius, focus_dist;
+    float t0, t1;
+} rt_camera;
+
+const char* rt_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* cameras — constructors of cu_Cameras.cuh:16-28, 40-52, 73-85        */
+/* ------------------------------------------------------------------ */
+int rt_camera_pinhole(const float lookfrom[3], const float lookat[3], const float up[3],
+                      float vfov, float aspect, rt_camera* out);
+int rt_camera_defocus(const float lookfrom[3], const float lookat[3], const float up[3],
+                      float vfov, float aspect, float aperture, float focus_dist, rt_camera* out);
+int rt_camera_motion(const float lookfrom[3], const float lookat[3], const float up[3],
+                     float vfov, float aspect, float time0, float time1, rt_camera* out);
+
+/* ------------------------------------------------------------------ */
+/* scene construction — host side, replaces SphereHandle / newOnDevice /
+ * BVH_Handle::Factory / HittableList / bvh_node / SceneBook2BVH::Factory  */
+/* ------------------------------------------------------------------ */
+typedef struct rt_scene rt_scene;
+
+int rt_scene_create(rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+
+/* newOnDevice<LambertianAbstract<G>>(albedo) etc. (Scenes.cu:222,235,242,248).
+ * Returns the material index in *out_id.                                    */
+int rt_scene_add_material(rt_scene* s, uint32_t type, const float albedo[3], float param,
+                          const float albedo2[3], int32_t* out_id);
+/* SphereHandle::MakeSphere / MakeMovingSphere (SphereHittable.cuh:134-154).
+ * Returns the primitive index; bounds as getSphereBounds/getMovingSphereBounds
+ * (SphereHittable.cu:52-54, 85-89).                                          */
+int rt_scene_add_sphere(rt_scene* s, const float center[3], float radius, int32_t mat, int32_t* out_prim);
+int rt_scene_add_moving_sphere(rt_scene* s, const float c0[3], const float c1[3], float radius,
+                               int32_t mat, int32_t* out_prim);
+int rt_scene_prim_bounds(const rt_scene* s, int32_t prim, float out_min[3], float out_max[3]);
+
+/* BVH_Handle::Factory::BuildBVH_TopDown -> _build_bvh_rec1 (BVH.cu:166-210):
+ * median split on the longest axis, leaf size 1, post-order numbering, root =
+ * last node.  Reorders the primitives (hittables[] = sorted order, :174-177). */
+int rt_scene_build_bvh_topdown(rt_scene* s);
+/* _build_bvh_rec2 + _find_optimal_split + _partition_by_split (BVH.cu:212-304) */
+int rt_scene_build_bvh_sah(rt_scene* s);
+/* BuildBVH_BottomUp (BVH.cu:315-384), O(n^3) agglomerative                    */
+int rt_scene_build_bvh_bottomup(rt_scene* s);
+/* HittableList(objects, count, bounds) (HittableList.cuh:19)                  */
+int rt_scene_set_world_list(rt_scene* s);
+/* bvh_node(left,right,bounds) (bvh_node.cuh:17).  Child refs: >= 0 node
+ * returned earlier, < 0 primitive (-prim - 1).  bounds may be NULL = union of
+ * the children's bounds.                                                      */
+int rt_scene_add_bvh_node(rt_scene* s, int32_t left_ref, int32_t right_ref,
+                          const float bmin[3], const float bmax[3], int32_t* out_ref);
+int rt_scene_set_world_node_tree(rt_scene* s, int32_t root_ref);
+
+/* SceneBook2BVH::getWorldPtr (Scenes.h:72) resolved to flat arrays.  Pointers
+ * stay valid until the scene is modified or destroyed.                        */
+int rt_scene_get_flat(const rt_scene* s, rt_world_flat* out);
+
+/* Prefab scenes.  The reference draws its layout from cuRAND's host XORWOW
+ * stream (cuHostRND, seed 1984), which cannot be reproduced without cuRAND;
+ * these use the library's own counter-based host stream with the reference's
+ * draw pattern (Scenes.cu:229-252; test.cpp:36-62).
+ *  book1_final   : 488 static spheres + BVH   (disabled SceneBook1, Scenes.cu:57-115)
+ *  book2_moving  : moving Lambertians + BVH   (live SceneBook2BVH, Scenes.cu:219-270)
+ *  three_spheres : Book-1 three-spheres scene as a HittableList (config 1)    */
+int rt_scene_book1_final(uint64_t seed, rt_scene** out);
+int rt_scene_book2_moving(uint64_t seed, rt_scene** out);
+int rt_scene_three_spheres(rt_scene** out);
+
+/* ------------------------------------------------------------------ */
+/* Renderer — main/src/Renderer.h:38-46                                */
+/* ------------------------------------------------------------------ */
+typedef struct rt_renderer rt_renderer;
+
+typedef struct rt_render_config {
+    uint32_t width, height;       /* Renderer::MakeRenderer args 1-2 */
+    uint32_t samples_per_pixel;   /* arg 3 */
+    uint32_t max_depth;           /* arg 4 */
+    uint64_t seed;                /* reference hard-codes 1984 (Renderer.cu:51) */
+    int32_t  device;              /* HIP device ordinal */
+    /* tile sharding across the GPUs of one node: this renderer owns the 8x8
+     * pixel tiles t with t % world_size == rank (row-major tile order).      */
+    uint32_t rank, world_size;
+    uint32_t variant;             /* 0 = default kernel; others select tuning variants (bench A/B) */
+} rt_render_config;
+
+/* Renderer::MakeRenderer (Renderer.cu:31-67).  Copies the flat world and the
+ * camera; allocates the device framebuffer.  No RNG-state array is needed
+ * (counter-based RNG), so init_random_states (Renderer.cu:22-29) has no twin. */
+int rt_renderer_create(const rt_render_config* cfg, const rt_camera* cam,
+                       const rt_world_flat* world, rt_renderer** out);
+void rt_renderer_destroy(rt_renderer* r);
+
+/* Renderer::Render (Renderer.cu:111-137): blocking; launches on the
+ * renderer's own stream and waits.                                          */
+int rt_renderer_render(rt_renderer* r);
+/* Same launch on a caller-provided hipStream_t, no host synchronisation.
+ * d_out = device buffer for this rank's shard (rt_renderer_shard_floats
+ * floats) or NULL to use the renderer's own framebuffer.                    */
+int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float* d_out);
+/* HIP-event time of the last render launch(es) in ms (cudaTimer twin,
+ * Renderer.cu:127-136).  Synchronises on the events.                        */
+int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms);
+/* Renderer::DownloadRenderbuffer (Renderer.cu:94-96): width*height*4 floats,
+ * row-major, row 0 = bottom.  Only valid for world_size == 1.               */
+int rt_renderer_download(rt_renderer* r, float* host_rgba, size_t n_floats);
+/* Number of floats in this rank's compact shard (n_local_tiles * 64 * 4);
+ * identical on every rank.                                                  */
+int rt_renderer_shard_floats(const rt_renderer* r, size_t* out);
+/* Rank-0 side of the frame-end gather: `d_gathered` holds world_size shards
+ * back to back (rank-major); writes the row-major width*height*4 image.     */
+int rt_renderer_assemble(rt_renderer* r, const float* d_gathered, float* d_image, void* hip_stream);
+
+/* ------------------------------------------------------------------ */
+/* Device probes: run ONE hot-path function over an array of inputs on  */
+/* the GPU.  Used by the parity tests (per-function golden vectors) —   */
+/* the twin of google_testing/test.cpp's host-vs-device differential.   */
+/* All pointers are HOST pointers; the probes copy in/out themselves.   */
+/* ------------------------------------------------------------------ */
+/* aabb::intersects (aabb.cuh:30-44): boxes n*6 (min,max), rays n*6 (o,d),
+ * max_dist n -> hit n (0/1), dist n (only written when hit, else left 0).   */
+int rt_probe_aabb(int device, size_t n, const float* boxes, const float* rays, const float* max_dist,
+                  int32_t* out_hit, float* out_dist);
+/* _sphere_closest_intersection (SphereHittable.cuh:15-33): rays n*6,
+ * spheres n*4 (c,r) -> t n                                                   */
+int rt_probe_sphere(int device, size_t n, const float* rays, const float* spheres, float* out_t);
+/* Hittable::ClosestIntersection on a whole world: rays n*7 (o,d,time) ->
+ * hit n, t n, prim n, normal n*3                                             */
+int rt_probe_trace(int device, const rt_world_flat* world, size_t n, const float* rays,
+                   int32_t* out_hit, float* out_t, int32_t* out_prim, float* out_normal);
+/* Material::Scatter (cu_materials.cuh:52,77,115,27): per case a material,
+ * in-ray n*7, hit distance n, outward normal n*3, RNG key (pixel,sample) n*2
+ * -> scattered n (0/1), out ray n*7, attenuation n*3, draws consumed n       */
+int rt_probe_scatter(int device, uint64_t seed, size_t n, const rt_material* mats, const float* rays,
+                     const float* dist, const float* normals, const uint32_t* keys,
+                     int32_t* out_scattered, float* out_rays, float* out_atten, uint32_t* out_draws);
+/* camera sample_ray (cu_Cameras.cuh:27,54,87): st n*2, keys n*2 -> ray n*7   */
+int rt_probe_camera(int device, uint64_t seed, const rt_camera* cam, size_t n, const float* st,
+                    const uint32_t* keys, float* out_rays, uint32_t* out_draws);
+/* one full sample (render_kernel body for one s + sample_world,
+ * Renderer.cu:139-181,198-204): keys n*2 (pixel gid, sample) -> radiance n*3 */
+int rt_probe_radiance(const rt_render_config* cfg, const rt_camera* cam, const rt_world_flat* world,
+                      size_t n, const uint32_t* keys, float* out_radiance);
+/* google_testing/test.cpp:112-135 `_sphere_index_ker`: brute-force nearest
+ * sphere index per pixel, pinhole camera, NDC = x/(w-1)*2-1 (test.cpp:118-119) */
+int rt_probe_sphere_index(int device, const rt_camera* cam, uint32_t width, uint32_t height,
+                          size_t n_spheres, const float* spheres, int32_t* out_index);
+/* raw uniforms of the counter-based RNG: keys n*2, n_draws each -> n*n_draws */
+int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t* keys, uint32_t n_draws, float* out);
+
+/* library / device info */
+int rt_device_count(int* out);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT06_H */

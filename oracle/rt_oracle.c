@@ -1,0 +1,898 @@
+/*
+ * rt_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ * See rt_oracle.h for the pin status ("parity unpinned" above the GLM
+ * vocabulary) and the arithmetic contract.  Build: oracle/Makefile
+ * (gcc -O2 -ffp-contract=off, no fast-math).
+ *
+ * Citations are file:line under /root/reference/ ; "…/geometry" =
+ * main/src/rt_engine/geometry, "…/shaders" = main/src/rt_engine/shaders,
+ * "glm/" = Libraries/include/glm.
+ */
+#include "rt_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_MISS_DIST 3.402823466e+38F /* _MISS_DIST, rt_engine/ray_data.cuh:17 */
+#define ORC_STACK 32                   /* _PRIO_QUEUE_ELEM_COUNT, …/geometry/BVH.cu:17 */
+#define ORC_PRIM_MOVING 0x80000000u
+
+/* ------------------------------------------------------------------ */
+/* GLM vocabulary                                                      */
+/* ------------------------------------------------------------------ */
+typedef orc_v3 v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+static inline void st3(float* p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+static inline v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 divv(v3 a, v3 b) { return V(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline v3 muls(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 divs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+static inline v3 neg(v3 a) { return V(-a.x, -a.y, -a.z); }
+
+/* glm/detail/func_common.inl:17-30: min = (y<x)?y:x ; max = (x<y)?y:x */
+static inline float gmin(float x, float y) { return (y < x) ? y : x; }
+static inline float gmax(float x, float y) { return (x < y) ? y : x; }
+static inline v3 vmin(v3 a, v3 b) { return V(gmin(a.x, b.x), gmin(a.y, b.y), gmin(a.z, b.z)); }
+static inline v3 vmax(v3 a, v3 b) { return V(gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)); }
+/* glm/gtx/component_wise.inl:111-126 */
+static inline float comp_min(v3 a) { float r = a.x; r = gmin(r, a.y); r = gmin(r, a.z); return r; }
+static inline float comp_max(v3 a) { float r = a.x; r = gmax(r, a.y); r = gmax(r, a.z); return r; }
+/* glm/detail/func_geometric.inl:48-56: tmp = a*b; tmp.x + tmp.y + tmp.z */
+static inline float dot(v3 a, v3 b) { v3 t = mul(a, b); return t.x + t.y + t.z; }
+/* glm/detail/func_geometric.inl:70-81 */
+static inline v3 cross(v3 x, v3 y) {
+    return V(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
+}
+/* glm/detail/func_geometric.inl:84-93 + func_exponential.inl:134-139:
+ * v * inversesqrt(dot(v,v)), inversesqrt(x) = 1 / sqrt(x) */
+static inline v3 normalize(v3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return muls(a, inv); }
+/* glm/detail/func_geometric.inl:104-110: I - N * dot(N,I) * 2 */
+static inline v3 reflect(v3 i, v3 n) { return sub(i, muls(muls(n, dot(n, i)), 2.0f)); }
+/* glm/detail/func_geometric.inl:113-123 */
+static inline v3 refract(v3 i, v3 n, float eta) {
+    float dv = dot(n, i);
+    float k = 1.0f - eta * eta * (1.0f - dv * dv);
+    if (k >= 0.0f) return sub(muls(i, eta), muls(n, eta * dv + sqrtf(k)));
+    return V(0.0f, 0.0f, 0.0f);
+}
+/* glm/detail/func_common.inl:104-112,124-132: x*(1-a) + y*a */
+static inline v3 mix3(v3 x, v3 y, float a) { return add(muls(x, 1.0f - a), muls(y, a)); }
+static inline float mix1(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+/* main/src/utilities/glm_utils.h:15-25, epsilon 1e-9f */
+static inline int near_zero(v3 a) {
+    if (fabsf(a.x) > 1e-9f) return 0;
+    if (fabsf(a.y) > 1e-9f) return 0;
+    if (fabsf(a.z) > 1e-9f) return 0;
+    return 1;
+}
+/* glm_utils.h:27-35: sum{} ; sum += v[i]*v[i] */
+static inline float length2_3(v3 a) { float s = 0.0f; s += a.x * a.x; s += a.y * a.y; s += a.z * a.z; return s; }
+static inline float length2_2(float x, float y) { float s = 0.0f; s += x * x; s += y * y; return s; }
+/* glm_utils.h:64-67: a + (b - a) * f */
+static inline v3 lerp3(v3 a, v3 b, float f) { return add(a, muls(sub(b, a), f)); }
+/* glm/detail/func_trigonometric.inl:9-14 */
+static inline float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+
+float orc_glm_dot(const float a[3], const float b[3]) { return dot(ld3(a), ld3(b)); }
+void orc_glm_cross(const float a[3], const float b[3], float out[3]) { st3(out, cross(ld3(a), ld3(b))); }
+void orc_glm_normalize(const float a[3], float out[3]) { st3(out, normalize(ld3(a))); }
+void orc_glm_reflect(const float i[3], const float n[3], float out[3]) { st3(out, reflect(ld3(i), ld3(n))); }
+void orc_glm_refract(const float i[3], const float n[3], float eta, float out[3]) { st3(out, refract(ld3(i), ld3(n), eta)); }
+void orc_glm_mix3(const float a[3], const float b[3], float t, float out[3]) { st3(out, mix3(ld3(a), ld3(b), t)); }
+float orc_glm_mix1(float a, float b, float t) { return mix1(a, b, t); }
+void orc_glm_min3(const float a[3], const float b[3], float out[3]) { st3(out, vmin(ld3(a), ld3(b))); }
+void orc_glm_max3(const float a[3], const float b[3], float out[3]) { st3(out, vmax(ld3(a), ld3(b))); }
+float orc_glm_compmax(const float a[3]) { return comp_max(ld3(a)); }
+float orc_glm_compmin(const float a[3]) { return comp_min(ld3(a)); }
+int orc_glm_near_zero(const float a[3]) { return near_zero(ld3(a)); }
+float orc_glm_length2(const float a[3]) { return length2_3(ld3(a)); }
+void orc_glm_lerp(const float a[3], const float b[3], float t, float out[3]) { st3(out, lerp3(ld3(a), ld3(b), t)); }
+float orc_glm_radians(float deg) { return radians(deg); }
+/* main/src/Renderer.cu:209-211: clamp(x,0,1) = min(max(x,0),1)
+ * (glm/detail/func_common.inl:240-246), then sqrt */
+static inline v3 clamp01_sqrt(v3 a) {
+    v3 c = vmin(vmax(a, V(0.0f, 0.0f, 0.0f)), V(1.0f, 1.0f, 1.0f));
+    return V(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
+}
+void orc_glm_clamp01_sqrt(const float a[3], float out[3]) { st3(out, clamp01_sqrt(ld3(a))); }
+
+/* ------------------------------------------------------------------ */
+/* RNG — the build's own counter-based generator (Philox4x32-10).      */
+/* Replaces cuRandom (utilities/cuda_utilities/cuRandom.cuh:10-41);    */
+/* keeps its draw ORDER and its (0,1] range (curand_uniform).          */
+/* counter = (draw/4, sample, pixel, stream), key = seed lo/hi;         */
+/* uniform = ((word >> 8) + 1) * 2^-24  (exact in fp32).               */
+/* ------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct {
+    uint32_t key[2];
+    uint32_t sample, pixel, stream;
+    uint32_t draw;
+    uint32_t buf[4];
+} rng_t;
+
+static inline void rng_init(rng_t* g, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream) {
+    g->key[0] = (uint32_t)seed; g->key[1] = (uint32_t)(seed >> 32);
+    g->sample = sample; g->pixel = pixel; g->stream = stream; g->draw = 0;
+}
+/* cuRandom::next(), cuRandom.cuh:21 (curand_uniform in (0,1]) */
+static inline float rng_next(rng_t* g) {
+    if ((g->draw & 3u) == 0u) {
+        uint32_t ctr[4] = {g->draw >> 2, g->sample, g->pixel, g->stream};
+        orc_philox4x32_10(ctr, g->key, g->buf);
+    }
+    uint32_t w = g->buf[g->draw & 3u];
+    g->draw++;
+    return (float)((w >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24 */
+}
+void orc_rng_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, float* out) {
+    rng_t g; rng_init(&g, seed, pixel, sample, stream);
+    for (uint32_t i = 0; i < n; i++) out[i] = rng_next(&g);
+}
+/* glm::cuRandomInUnit<2>, utilities/glm_utils.h:84-90 */
+static inline void rng_in_unit2(rng_t* g, float* ox, float* oy) {
+    for (;;) {
+        float x = rng_next(g) * 2.0f - 1.0f;
+        float y = rng_next(g) * 2.0f - 1.0f;
+        if (length2_2(x, y) < 1.0f) { *ox = x; *oy = y; return; }
+    }
+}
+/* glm::cuRandomOnUnit<3>, utilities/glm_utils.h:92-98 */
+static inline v3 rng_on_unit3(rng_t* g) {
+    for (;;) {
+        v3 v;
+        v.x = rng_next(g) * 2.0f - 1.0f;
+        v.y = rng_next(g) * 2.0f - 1.0f;
+        v.z = rng_next(g) * 2.0f - 1.0f;
+        if (!near_zero(v) && length2_3(v) < 1.0f) return normalize(v);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* rays, boxes, spheres                                                */
+/* ------------------------------------------------------------------ */
+typedef struct { v3 o, d; float time; } ray_t;                 /* Ray, rt_engine/ray_data.cuh:8-15 */
+typedef struct { float distance; v3 normal; int32_t prim; uint32_t mat; } rec_t; /* RayPayload + TraceRecord, ray_data.cuh:33-40, SphereHittable.cuh:38-41 */
+
+static inline v3 ray_at(const ray_t* r, float t) { return add(r->o, muls(r->d, t)); } /* ray_data.cuh:14 */
+
+/* aabb::intersects, …/geometry/aabb.cuh:30-44 */
+static inline int aabb_intersects(v3 bmin_c, v3 bmax_c, const ray_t* ray, float ray_max_dist, float* dist) {
+    v3 bmin = divv(sub(bmin_c, ray->o), ray->d);
+    v3 bmax = divv(sub(bmax_c, ray->o), ray->d);
+    v3 tmp_min = vmin(bmin, bmax);
+    bmax = vmax(bmin, bmax);
+    bmin = tmp_min;
+    float tmin = comp_max(bmin);
+    float tmax = comp_min(bmax);
+    int hit = tmin <= tmax && tmin < ray_max_dist && tmax > 0;
+    if (hit) *dist = tmin;
+    return hit;
+}
+
+/* _sphere_closest_intersection, …/geometry/SphereHittable.cuh:15-33 */
+static inline float sphere_closest_intersection(const ray_t* ray, v3 center, float radius) {
+    v3 oc = sub(ray->o, center);
+    float a = dot(ray->d, ray->d);
+    float hb = dot(ray->d, oc);
+    float c = dot(oc, oc) - radius * radius;
+    float d = hb * hb - a * c;
+    if (d <= 0) return ORC_MISS_DIST;
+    d = sqrtf(d);
+    float t = (-hb - d) / a;
+    if (t < 0.0f) {
+        t = (-hb + d) / a;
+        if (t < 0.0f) return ORC_MISS_DIST;
+    }
+    return t;
+}
+
+/* SphereHittable::ClosestIntersection (…/geometry/SphereHittable.cu:56-66) and
+ * MovingSphereHittable::ClosestIntersection (:91-102) */
+static inline int prim_closest_intersection(const orc_world* w, int32_t idx, const ray_t* ray, rec_t* rec,
+                                            orc_counters* cnt) {
+    const orc_prim* p = &w->prims[idx];
+    v3 center = ld3(p->c0);
+    if (p->mat & ORC_PRIM_MOVING) center = mix3(ld3(p->c0), ld3(p->c1), ray->time);
+    cnt->leaf_tests++;
+    float t = sphere_closest_intersection(ray, center, p->radius);
+    if (t >= rec->distance) return 0;
+    rec->mat = p->mat & ~ORC_PRIM_MOVING;
+    rec->distance = t;
+    rec->prim = idx;
+    rec->normal = divs(sub(ray_at(ray, rec->distance), center), p->radius);
+    return 1;
+}
+
+static inline int node_box(const orc_node* n, const ray_t* ray, float maxd, float* dist, orc_counters* cnt) {
+    cnt->box_tests++;
+    return aabb_intersects(ld3(n->min), ld3(n->max), ray, maxd, dist);
+}
+
+/* BVH::ClosestIntersection, …/geometry/BVH.cu:54-106 (non-priority-queue branch) */
+static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err) {
+    int32_t stack[ORC_STACK];
+    int head = 0;
+    const orc_node* nodes = w->nodes;
+    float root_dist;
+    if (!node_box(&nodes[w->root], ray, rec->distance, &root_dist, cnt)) return 0;
+    stack[head++] = w->root;
+    if ((uint32_t)head > cnt->max_stack) cnt->max_stack = head;
+    int hit_any = 0;
+    while (head != 0) {
+        int32_t idx = stack[--head];
+        const orc_node* node = &nodes[idx];
+        if (node->left == -1) {
+            hit_any |= prim_closest_intersection(w, node->right, ray, rec, cnt);
+            continue;
+        }
+        float left_dist = ORC_MISS_DIST, right_dist = ORC_MISS_DIST;
+        int32_t left_idx = node->left, right_idx = node->right;
+        node_box(&nodes[left_idx], ray, rec->distance, &left_dist, cnt);
+        node_box(&nodes[right_idx], ray, rec->distance, &right_dist, cnt);
+        if (left_dist > right_dist) {
+            int32_t ti = left_idx; left_idx = right_idx; right_idx = ti;
+            float tf = left_dist; left_dist = right_dist; right_dist = tf;
+        }
+        if (head + 2 > ORC_STACK) { *err = 4; return hit_any; }
+        if (right_dist < rec->distance) stack[head++] = right_idx;
+        if (left_dist < rec->distance) stack[head++] = left_idx;
+        if ((uint32_t)head > cnt->max_stack) cnt->max_stack = head;
+    }
+    return hit_any;
+}
+
+/* HittableList::ClosestIntersection, …/geometry/HittableList.cuh:21-34 */
+static int list_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt) {
+    float d;
+    cnt->box_tests++;
+    if (!aabb_intersects(ld3(w->bounds_min), ld3(w->bounds_max), ray, rec->distance, &d)) return 0;
+    int hit_any = 0;
+    for (uint32_t i = 0; i < w->n_prims; i++)
+        if (prim_closest_intersection(w, (int32_t)i, ray, rec, cnt)) hit_any = 1;
+    return hit_any;
+}
+
+/* bvh_node::ClosestIntersection, …/geometry/bvh_node.cuh:19-24 (recursive, both
+ * children, unordered).  ref >= 0 node, ref < 0 primitive (-ref-1). */
+static int tree_closest_intersection(const orc_world* w, int32_t ref, const ray_t* ray, rec_t* rec,
+                                     orc_counters* cnt, int depth, int* err) {
+    if (ref < 0) return prim_closest_intersection(w, -ref - 1, ray, rec, cnt);
+    if (depth > 4096) { *err = 4; return 0; }
+    const orc_node* n = &w->nodes[ref];
+    float d;
+    if (!node_box(n, ray, rec->distance, &d, cnt)) return 0;
+    int hit = tree_closest_intersection(w, n->left, ray, rec, cnt, depth + 1, err);
+    hit |= tree_closest_intersection(w, n->right, ray, rec, cnt, depth + 1, err);
+    return hit;
+}
+
+static inline int world_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err) {
+    cnt->rays++;
+    switch (w->kind) {
+    case 0: return bvh_closest_intersection(w, ray, rec, cnt, err);
+    case 1: return list_closest_intersection(w, ray, rec, cnt);
+    default: return tree_closest_intersection(w, w->root, ray, rec, cnt, 0, err);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* materials                                                           */
+/* ------------------------------------------------------------------ */
+/* reflectance, …/shaders/cu_materials.cuh:99-104 ; powf(x,5) -> x2,x4,x5 (see header) */
+static inline float reflectance(float cos_theta, float ior_ratio) {
+    float r0 = (1 - ior_ratio) / (1 + ior_ratio);
+    r0 = r0 * r0;
+    float x = 1 - cos_theta;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    float x5 = x4 * x;
+    return r0 + (1 - r0) * x5;
+}
+
+/* checker_texture::value, …/shaders/cu_Textures.cuh:31-39 (ivec3 truncation) */
+static inline v3 checker_value(const orc_material* m, v3 pos) {
+    v3 sp = muls(pos, m->param);
+    int ix = (int)sp.x, iy = (int)sp.y, iz = (int)sp.z;
+    int sum = 0; sum += ix; sum += iy; sum += iz;
+    return (sum % 2 == 0) ? ld3(m->albedo) : ld3(m->albedo2);
+}
+
+/* Material::Scatter for the four material classes:
+ *  LambertianAbstract  …/shaders/cu_materials.cuh:52-64
+ *  MetalAbstract       :77-95
+ *  DielectricAbstract  :115-143
+ *  LambertianTexture   :27-40 */
+static int material_scatter(const orc_material* m, const ray_t* in_ray, const rec_t* rec, rng_t* g,
+                            ray_t* out, v3* attenuation) {
+    v3 normal = rec->normal;
+    switch (m->type) {
+    case 0:
+    case 3: {
+        v3 ray_dir = add(normal, rng_on_unit3(g));
+        if (near_zero(ray_dir)) return 0;
+        out->o = ray_at(in_ray, rec->distance); out->d = ray_dir; out->time = in_ray->time;
+        *attenuation = (m->type == 0) ? ld3(m->albedo) : checker_value(m, ray_at(in_ray, rec->distance));
+        return 1;
+    }
+    case 1: {
+        v3 refl = reflect(in_ray->d, normal);
+        v3 scatter_dir = add(refl, muls(rng_on_unit3(g), m->param));
+        if (dot(scatter_dir, normal) < 0 || near_zero(scatter_dir)) return 0;
+        out->o = ray_at(in_ray, rec->distance); out->d = scatter_dir; out->time = in_ray->time;
+        *attenuation = ld3(m->albedo);
+        return 1;
+    }
+    default: {
+        float ior = m->param;
+        int hit_backface = dot(in_ray->d, normal) > 0; /* isBackfacing, ray_data.cuh:44-46 */
+        if (hit_backface) normal = neg(normal);
+        float ior_ratio = hit_backface ? ior : 1 / ior;
+        v3 unit_dir = normalize(in_ray->d);
+        float cos_theta = fminf(dot(neg(unit_dir), normal), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        float reflect_prob = reflectance(cos_theta, ior_ratio);
+        v3 scatter_dir;
+        if (ior_ratio * sin_theta > 1.0f || reflect_prob > rng_next(g))
+            scatter_dir = reflect(unit_dir, normal);
+        else
+            scatter_dir = refract(unit_dir, normal, ior_ratio);
+        out->o = ray_at(in_ray, rec->distance); out->d = scatter_dir; out->time = in_ray->time;
+        *attenuation = ld3(m->albedo);
+        return 1;
+    }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* cameras, …/shaders/cu_Cameras.cuh                                   */
+/* ------------------------------------------------------------------ */
+static void camera_basis(const float lookfrom[3], const float lookat[3], const float up[3], float vfov,
+                         float aspect, orc_camera* c, int prescale) {
+    float theta = radians(vfov);
+    float vh = tanf(theta * 0.5f);
+    float vw = vh * aspect;
+    v3 w = normalize(sub(ld3(lookat), ld3(lookfrom)));
+    v3 u = normalize(cross(ld3(up), w));
+    if (prescale) u = muls(u, vw);
+    v3 v = normalize(cross(w, u));
+    if (prescale) v = muls(v, vh);
+    memset(c, 0, sizeof(*c));
+    st3(c->o, ld3(lookfrom)); st3(c->u, u); st3(c->v, v); st3(c->w, w);
+    c->viewport_width = vw; c->viewport_height = vh;
+    c->t0 = 0.0f; c->t1 = 1.0f;
+}
+/* PinholeCamera ctor :16-25 */
+void orc_camera_pinhole(const float lookfrom[3], const float lookat[3], const float up[3], float vfov,
+                        float aspect, orc_camera* out) {
+    camera_basis(lookfrom, lookat, up, vfov, aspect, out, 1);
+    out->type = 0;
+}
+/* DefocusBlurCamera ctor :40-52 */
+void orc_camera_defocus(const float lookfrom[3], const float lookat[3], const float up[3], float vfov,
+                        float aspect, float aperture, float focus_dist, orc_camera* out) {
+    camera_basis(lookfrom, lookat, up, vfov, aspect, out, 0);
+    out->type = 1;
+    out->lens_radius = aperture * 0.5f;
+    out->focus_dist = focus_dist;
+}
+/* MotionBlurCamera ctor :73-85 */
+void orc_camera_motion(const float lookfrom[3], const float lookat[3], const float up[3], float vfov,
+                       float aspect, float t0, float t1, orc_camera* out) {
+    camera_basis(lookfrom, lookat, up, vfov, aspect, out, 1);
+    out->type = 2;
+    out->t0 = t0; out->t1 = t1;
+}
+
+/* sample_ray :27-30 (pinhole), :54-64 (defocus), :87-89 (motion) */
+static inline ray_t camera_sample_ray(const orc_camera* c, float s, float t, rng_t* g) {
+    ray_t r;
+    v3 o = ld3(c->o), u = ld3(c->u), v = ld3(c->v), w = ld3(c->w);
+    if (c->type == 1) {
+        float dx, dy;
+        rng_in_unit2(g, &dx, &dy);
+        v3 offset = add(muls(u, dx), muls(v, dy));
+        offset = muls(offset, c->lens_radius);
+        v3 forward = muls(w, c->focus_dist);
+        v3 hori = muls(muls(u, c->viewport_width), c->focus_dist);
+        v3 vert = muls(muls(v, c->viewport_height), c->focus_dist);
+        r.o = add(o, offset);
+        r.d = sub(add(add(forward, muls(hori, s)), muls(vert, t)), offset);
+        r.time = 0.0f;
+    } else {
+        r.o = o;
+        r.d = add(add(w, muls(u, s)), muls(v, t));
+        r.time = (c->type == 2) ? mix1(c->t0, c->t1, rng_next(g)) : 0.0f;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* sample_world, main/src/Renderer.cu:139-181                          */
+/* ------------------------------------------------------------------ */
+static v3 sample_world(const orc_world* w, ray_t cur_ray, uint32_t max_depth, rng_t* g, orc_counters* cnt, int* err) {
+    v3 accum_attenuation = V(1.0f, 1.0f, 1.0f);
+    for (uint32_t i = 0; i < max_depth; i++) {
+        rec_t rec; rec.distance = ORC_MISS_DIST; rec.prim = -1; rec.mat = 0; rec.normal = V(0, 0, 0);
+        if (!world_closest_intersection(w, &cur_ray, &rec, cnt, err)) {
+            float t = normalize(cur_ray.d).y * 0.5f + 0.5f;
+            v3 sky = lerp3(V(0.1f, 0.2f, 0.4f), V(0.9f, 0.9f, 0.99f), t);
+            return mul(accum_attenuation, sky);
+        }
+        cnt->shaded_hits++;
+        ray_t scattered; v3 attenuation;
+        if (!material_scatter(&w->materials[rec.mat], &cur_ray, &rec, g, &scattered, &attenuation))
+            return V(0.0f, 0.0f, 0.0f);
+        accum_attenuation = mul(accum_attenuation, attenuation);
+        cur_ray = scattered;
+        cur_ray.o = add(cur_ray.o, muls(cur_ray.d, 0.001f));
+    }
+    return V(0.0f, 0.0f, 0.0f);
+}
+
+/* one sample of render_kernel's loop body, Renderer.cu:198-204.  The RNG is
+ * keyed per (pixel, sample) instead of one XORWOW stream per pixel
+ * (Renderer.cu:191) — SURVEY.md Appendix A item 7. */
+static inline v3 one_sample(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height,
+                            uint32_t max_depth, uint64_t seed, uint32_t gid, uint32_t s, orc_counters* cnt, int* err) {
+    uint32_t x = gid % width, y = gid / width;
+    float psx = 1.0f / (float)width, psy = 1.0f / (float)height;
+    float ndcx = ((float)x + 0.5f) * psx * 2.0f - 1.0f;
+    float ndcy = ((float)y + 0.5f) * psy * 2.0f - 1.0f;
+    rng_t g; rng_init(&g, seed, gid, s, 0u);
+    float jx, jy;
+    rng_in_unit2(&g, &jx, &jy);
+    float sx = ndcx + jx * psx;
+    float sy = ndcy + jy * psy;
+    ray_t ray = camera_sample_ray(cam, sx, sy, &g);
+    v3 rad = sample_world(w, ray, max_depth, &g, cnt, err);
+    cnt->samples++;
+    cnt->rng_draws += g.draw;
+    return rad;
+}
+
+/* render_kernel, Renderer.cu:183-217 (one pixel) */
+static void render_pixel(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height,
+                         uint32_t spp, uint32_t max_depth, uint64_t seed, uint32_t x, uint32_t y,
+                         float* out_rgba, orc_counters* cnt, int* err) {
+    uint32_t gid = y * width + x;
+    v3 radiance = V(0.0f, 0.0f, 0.0f);
+    for (uint32_t s = 0; s < spp; s++)
+        radiance = add(radiance, one_sample(w, cam, width, height, max_depth, seed, gid, s, cnt, err));
+    radiance = muls(radiance, 1.0f / (float)spp);
+    v3 col = clamp01_sqrt(radiance);
+    float* o = out_rgba + (size_t)gid * 4;
+    o[0] = col.x; o[1] = col.y; o[2] = col.z; o[3] = 1.0f;
+}
+
+typedef struct {
+    const orc_world* w; const orc_camera* cam;
+    uint32_t width, height, spp, max_depth; uint64_t seed;
+    float* out; uint32_t* next_row; orc_counters cnt; int err;
+} job_t;
+
+static void* render_worker(void* arg) {
+    job_t* j = (job_t*)arg;
+    for (;;) {
+        uint32_t y = __atomic_fetch_add(j->next_row, 1u, __ATOMIC_RELAXED);
+        if (y >= j->height) break;
+        for (uint32_t x = 0; x < j->width; x++)
+            render_pixel(j->w, j->cam, j->width, j->height, j->spp, j->max_depth, j->seed, x, y, j->out, &j->cnt, &j->err);
+    }
+    return NULL;
+}
+
+int orc_render(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height, uint32_t spp,
+               uint32_t max_depth, uint64_t seed, int n_threads, float* out_rgba, orc_counters* counters) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    job_t* jobs = (job_t*)calloc((size_t)n_threads, sizeof(job_t));
+    pthread_t* th = (pthread_t*)calloc((size_t)n_threads, sizeof(pthread_t));
+    uint32_t next_row = 0;
+    for (int i = 0; i < n_threads; i++) {
+        jobs[i].w = w; jobs[i].cam = cam; jobs[i].width = width; jobs[i].height = height;
+        jobs[i].spp = spp; jobs[i].max_depth = max_depth; jobs[i].seed = seed;
+        jobs[i].out = out_rgba; jobs[i].next_row = &next_row;
+    }
+    if (n_threads == 1) render_worker(&jobs[0]);
+    else {
+        for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, render_worker, &jobs[i]);
+        for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+    }
+    int err = 0;
+    orc_counters total; memset(&total, 0, sizeof(total));
+    for (int i = 0; i < n_threads; i++) {
+        if (jobs[i].err) err = jobs[i].err;
+        total.samples += jobs[i].cnt.samples; total.rays += jobs[i].cnt.rays;
+        total.box_tests += jobs[i].cnt.box_tests; total.leaf_tests += jobs[i].cnt.leaf_tests;
+        total.shaded_hits += jobs[i].cnt.shaded_hits; total.rng_draws += jobs[i].cnt.rng_draws;
+        if (jobs[i].cnt.max_stack > total.max_stack) total.max_stack = jobs[i].cnt.max_stack;
+    }
+    if (counters) *counters = total;
+    free(jobs); free(th);
+    return err;
+}
+
+/* ------------------------------------------------------------------ */
+/* batch entry points (twins of rt_probe_*)                            */
+/* ------------------------------------------------------------------ */
+static inline ray_t ld_ray6(const float* p) { ray_t r; r.o = ld3(p); r.d = ld3(p + 3); r.time = 0.0f; return r; }
+static inline ray_t ld_ray7(const float* p) { ray_t r; r.o = ld3(p); r.d = ld3(p + 3); r.time = p[6]; return r; }
+static inline void st_ray7(float* p, const ray_t* r) { st3(p, r->o); st3(p + 3, r->d); p[6] = r->time; }
+
+void orc_aabb_batch(size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out_hit, float* out_dist) {
+    for (size_t i = 0; i < n; i++) {
+        ray_t r = ld_ray6(rays + 6 * i);
+        float d = 0.0f;
+        out_hit[i] = aabb_intersects(ld3(boxes + 6 * i), ld3(boxes + 6 * i + 3), &r, max_dist[i], &d);
+        out_dist[i] = d;
+    }
+}
+void orc_sphere_batch(size_t n, const float* rays, const float* spheres, float* out_t) {
+    for (size_t i = 0; i < n; i++) {
+        ray_t r = ld_ray6(rays + 6 * i);
+        out_t[i] = sphere_closest_intersection(&r, ld3(spheres + 4 * i), spheres[4 * i + 3]);
+    }
+}
+int orc_trace_batch(const orc_world* w, size_t n, const float* rays, int32_t* out_hit, float* out_t, int32_t* out_prim, float* out_normal) {
+    orc_counters cnt; memset(&cnt, 0, sizeof(cnt));
+    int err = 0;
+    for (size_t i = 0; i < n; i++) {
+        ray_t r = ld_ray7(rays + 7 * i);
+        rec_t rec; rec.distance = ORC_MISS_DIST; rec.prim = -1; rec.mat = 0; rec.normal = V(0, 0, 0);
+        out_hit[i] = world_closest_intersection(w, &r, &rec, &cnt, &err);
+        out_t[i] = rec.distance; out_prim[i] = rec.prim; st3(out_normal + 3 * i, rec.normal);
+    }
+    return err;
+}
+void orc_scatter_batch(uint64_t seed, size_t n, const orc_material* mats, const float* rays, const float* dist,
+                       const float* normals, const uint32_t* keys, int32_t* out_scattered, float* out_rays,
+                       float* out_atten, uint32_t* out_draws) {
+    for (size_t i = 0; i < n; i++) {
+        ray_t in = ld_ray7(rays + 7 * i);
+        rec_t rec; rec.distance = dist[i]; rec.normal = ld3(normals + 3 * i); rec.prim = 0; rec.mat = 0;
+        rng_t g; rng_init(&g, seed, keys[2 * i], keys[2 * i + 1], 0u);
+        ray_t out; out.o = V(0, 0, 0); out.d = V(0, 0, 0); out.time = 0.0f;
+        v3 att = V(0, 0, 0);
+        out_scattered[i] = material_scatter(&mats[i], &in, &rec, &g, &out, &att);
+        st_ray7(out_rays + 7 * i, &out); st3(out_atten + 3 * i, att); out_draws[i] = g.draw;
+    }
+}
+void orc_camera_batch(uint64_t seed, const orc_camera* cam, size_t n, const float* st, const uint32_t* keys,
+                      float* out_rays, uint32_t* out_draws) {
+    for (size_t i = 0; i < n; i++) {
+        rng_t g; rng_init(&g, seed, keys[2 * i], keys[2 * i + 1], 0u);
+        ray_t r = camera_sample_ray(cam, st[2 * i], st[2 * i + 1], &g);
+        st_ray7(out_rays + 7 * i, &r); out_draws[i] = g.draw;
+    }
+}
+int orc_radiance_batch(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height, uint32_t max_depth,
+                       uint64_t seed, size_t n, const uint32_t* keys, float* out_radiance) {
+    orc_counters cnt; memset(&cnt, 0, sizeof(cnt));
+    int err = 0;
+    for (size_t i = 0; i < n; i++)
+        st3(out_radiance + 3 * i, one_sample(w, cam, width, height, max_depth, seed, keys[2 * i], keys[2 * i + 1], &cnt, &err));
+    return err;
+}
+/* SphereTest::_pixel_ground_truth, google_testing/test.cpp:87-106 */
+void orc_sphere_index(const orc_camera* cam, uint32_t width, uint32_t height, size_t n_spheres, const float* spheres, int32_t* out_index) {
+    for (uint32_t y = 0; y < height; y++)
+        for (uint32_t x = 0; x < width; x++) {
+            float u = (float)x / ((float)width - 1.0f) * 2 - 1;
+            float v = (float)y / ((float)height - 1.0f) * 2 - 1;
+            /* PinholeCamera::sample_ray, cu_Cameras.cuh:27-30 */
+            ray_t ray;
+            ray.o = ld3(cam->o);
+            ray.d = add(add(ld3(cam->w), muls(ld3(cam->u), u)), muls(ld3(cam->v), v));
+            ray.time = 0.0f;
+            float best = ORC_MISS_DIST;
+            int32_t result = -1;
+            for (size_t i = 0; i < n_spheres; i++) {
+                float dist = sphere_closest_intersection(&ray, ld3(spheres + 4 * i), spheres[4 * i + 3]);
+                if (dist < best) { result = (int32_t)i; best = dist; }
+            }
+            out_index[(size_t)y * width + x] = result;
+        }
+}
+
+/* ------------------------------------------------------------------ */
+/* scene generation and BVH builders (host side of the path)           */
+/* ------------------------------------------------------------------ */
+struct orc_scene {
+    orc_prim* prims; size_t n_prims;
+    orc_material* mats; size_t n_mats;
+    orc_node* nodes; size_t n_nodes, cap_nodes;
+    orc_world world;
+};
+
+typedef struct { v3 mn, mx; } box_t;
+static inline box_t box_empty(void) { box_t b = {V(1e9f, 1e9f, 1e9f), V(-1e9f, -1e9f, -1e9f)}; return b; } /* aabb(), aabb.cuh:17 */
+static inline box_t box_union(box_t a, box_t b) { box_t r = {vmin(a.mn, b.mn), vmax(a.mx, b.mx)}; return r; } /* aabb.cuh:19,24 */
+/* getSphereBounds / getMovingSphereBounds, SphereHittable.cu:52-54,85-89 */
+static box_t prim_bounds(const orc_prim* p) {
+    v3 r = V(p->radius, p->radius, p->radius);
+    box_t b0 = {sub(ld3(p->c0), r), add(ld3(p->c0), r)};
+    if (!(p->mat & ORC_PRIM_MOVING)) return b0;
+    box_t b1 = {sub(ld3(p->c1), r), add(ld3(p->c1), r)};
+    return box_union(b0, b1);
+}
+/* aabb::longest_axis, aabb.cuh:46-53 */
+static int box_longest_axis(box_t b) {
+    v3 s = sub(b.mx, b.mn);
+    s = V(fabsf(s.x), fabsf(s.y), fabsf(s.z));
+    if (s.x > s.y) return s.x > s.z ? 0 : 2;
+    return s.y > s.z ? 1 : 2;
+}
+/* aabb::surface_area, aabb.cuh:55-64 */
+static float box_surface_area(box_t b) {
+    v3 s = sub(b.mx, b.mn);
+    if (s.x < 0 || s.y < 0 || s.z < 0) return 0.0f;
+    float cost = 0.0f;
+    cost += s.x * s.y; cost += s.x * s.z; cost += s.y * s.z;
+    return 2.0f * cost;
+}
+static inline v3 box_centroid(box_t b) { return muls(add(b.mx, b.mn), 0.5f); } /* aabb.cuh:66-68 */
+static inline float v3_axis(v3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
+
+typedef struct { box_t b; orc_prim p; } item_t;
+typedef struct {
+    item_t* arr; item_t* tmp;
+    orc_scene* s;
+} builder_t;
+
+static int32_t push_node(orc_scene* s, box_t b, int32_t left, int32_t right) {
+    if (s->n_nodes == s->cap_nodes) {
+        s->cap_nodes = s->cap_nodes ? s->cap_nodes * 2 : 64;
+        s->nodes = (orc_node*)realloc(s->nodes, s->cap_nodes * sizeof(orc_node));
+    }
+    orc_node* n = &s->nodes[s->n_nodes];
+    st3(n->min, b.mn); st3(n->max, b.mx); n->left = left; n->right = right;
+    return (int32_t)(s->n_nodes++);
+}
+/* _get_partition_bounds, BVH.cu:306-312 */
+static box_t partition_bounds(builder_t* B, int start, int end) {
+    box_t b = box_empty();
+    for (int i = start; i < end; i++) b = box_union(b, B->arr[i].b);
+    return b;
+}
+/* std::sort by bounds.min[axis] (BVH.cu:195-199, aabb.cuh:78-88).  std::sort is
+ * unstable; the build fixes the tie order by using a STABLE merge sort.     */
+static void stable_sort_axis(builder_t* B, int start, int end, int axis) {
+    int n = end - start;
+    if (n < 2) return;
+    item_t* a = B->arr + start; item_t* t = B->tmp + start;
+    for (int width = 1; width < n; width *= 2) {
+        for (int lo = 0; lo < n; lo += 2 * width) {
+            int mid = lo + width < n ? lo + width : n;
+            int hi = lo + 2 * width < n ? lo + 2 * width : n;
+            int i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) {
+                /* take from the right run only if strictly less (stability) */
+                if (v3_axis(a[j].b.mn, axis) < v3_axis(a[i].b.mn, axis)) t[k++] = a[j++];
+                else t[k++] = a[i++];
+            }
+            while (i < mid) t[k++] = a[i++];
+            while (j < hi) t[k++] = a[j++];
+        }
+        memcpy(a, t, (size_t)n * sizeof(item_t));
+    }
+}
+/* _build_bvh_rec1, BVH.cu:180-210 */
+static int32_t build_rec1(builder_t* B, int start, int end) {
+    box_t bounds = partition_bounds(B, start, end);
+    int axis = box_longest_axis(bounds);
+    if (end - start == 1) return push_node(B->s, bounds, -1, start);
+    stable_sort_axis(B, start, end, axis);
+    int mid = (start + end) / 2;
+    int32_t l = build_rec1(B, start, mid);
+    int32_t r = build_rec1(B, mid, end);
+    return push_node(B->s, bounds, l, r);
+}
+/* _find_optimal_split, BVH.cu:241-279 */
+static void find_optimal_split(builder_t* B, int start, int end, box_t bounds, int* best_axis, float* best_split) {
+    const int split_points = 16;
+    float best_cost = 3.402823466e+38F;
+    *best_axis = 0; *best_split = 0.0f;
+    for (int axis = 0; axis < 3; axis++)
+        for (int split = 0; split < split_points; split++) {
+            float pos = ((float)split + 1.0f) / ((float)split_points + 1.0f);
+            pos = mix1(v3_axis(bounds.mn, axis), v3_axis(bounds.mx, axis), pos);
+            box_t lb = box_empty(), rb = box_empty();
+            int lc = 0, rc = 0;
+            for (int i = start; i < end; i++) {
+                box_t b = B->arr[i].b;
+                if (v3_axis(box_centroid(b), axis) < pos) { lb = box_union(lb, b); lc++; }
+                else { rb = box_union(rb, b); rc++; }
+            }
+            float cost = box_surface_area(lb) * (float)lc + box_surface_area(rb) * (float)rc;
+            if (cost < best_cost) { best_cost = cost; *best_axis = axis; *best_split = pos; }
+        }
+}
+/* _partition_by_split, BVH.cu:281-304 */
+static int partition_by_split(builder_t* B, int start, int end, int axis, float split_pos) {
+    int i = start, j = end;
+    while (i < j) {
+        if (v3_axis(box_centroid(B->arr[i].b), axis) < split_pos) i++;
+        else { item_t t = B->arr[i]; B->arr[i] = B->arr[--j]; B->arr[j] = t; }
+    }
+    return i;
+}
+/* _build_bvh_rec2, BVH.cu:212-239.  The reference recurses forever when a
+ * split leaves one side empty; the build falls back to the median split of
+ * rec1 for that range (documented fix).                          */
+static int32_t build_rec2(builder_t* B, int start, int end) {
+    box_t bounds = partition_bounds(B, start, end);
+    if (end - start == 1) return push_node(B->s, bounds, -1, start);
+    int axis; float split;
+    find_optimal_split(B, start, end, bounds, &axis, &split);
+    int mid = partition_by_split(B, start, end, axis, split);
+    if (mid == start || mid == end) {
+        stable_sort_axis(B, start, end, box_longest_axis(bounds));
+        mid = (start + end) / 2;
+    }
+    int32_t l = build_rec2(B, start, mid);
+    int32_t r = build_rec2(B, mid, end);
+    return push_node(B->s, bounds, l, r);
+}
+/* BuildBVH_BottomUp + _find_optimal_merge + _merge_nodes, BVH.cu:315-384 */
+typedef struct { box_t b; int count; int32_t idx; } bnode_t;
+static int32_t build_bottom_up(builder_t* B, int n) {
+    bnode_t* bn = (bnode_t*)malloc((size_t)n * sizeof(bnode_t));
+    int m = n;
+    for (int i = 0; i < n; i++) {
+        bn[i].b = B->arr[i].b; bn[i].count = 1;
+        bn[i].idx = push_node(B->s, B->arr[i].b, -1, i);
+    }
+    while (m > 1) {
+        float best_cost = 3.402823466e+38F;
+        int ba = 0, bb = 1;
+        for (int a = 0; a < m; a++)
+            for (int b = a + 1; b < m; b++) {
+                box_t nb = box_union(bn[a].b, bn[b].b);
+                float cost = box_surface_area(nb) * (float)(bn[a].count + bn[b].count);
+                if (cost < best_cost) { ba = a; bb = b; best_cost = cost; }
+            }
+        bnode_t merged;
+        merged.b = box_union(bn[ba].b, bn[bb].b);
+        merged.count = bn[ba].count + bn[bb].count;
+        merged.idx = push_node(B->s, merged.b, bn[ba].idx, bn[bb].idx);
+        /* erase bb then ba (ba < bb), push_back merged */
+        memmove(&bn[bb], &bn[bb + 1], (size_t)(m - bb - 1) * sizeof(bnode_t)); m--;
+        memmove(&bn[ba], &bn[ba + 1], (size_t)(m - ba - 1) * sizeof(bnode_t)); m--;
+        bn[m++] = merged;
+    }
+    int32_t root = bn[0].idx;
+    free(bn);
+    return root;
+}
+
+static uint32_t tree_leaf_depth(const orc_node* nodes, int32_t idx) {
+    if (nodes[idx].left == -1) return 0;
+    uint32_t a = tree_leaf_depth(nodes, nodes[idx].left), b = tree_leaf_depth(nodes, nodes[idx].right);
+    return 1 + (a > b ? a : b);
+}
+
+static void finish_scene(orc_scene* s, int builder) {
+    size_t n = s->n_prims;
+    orc_world* w = &s->world;
+    memset(w, 0, sizeof(*w));
+    box_t wb = box_empty();
+    for (size_t i = 0; i < n; i++) wb = box_union(wb, prim_bounds(&s->prims[i]));
+    if (builder == 3) {
+        w->kind = 1; w->root = 0;
+    } else {
+        builder_t B; B.s = s;
+        B.arr = (item_t*)malloc(n * sizeof(item_t)); B.tmp = (item_t*)malloc(n * sizeof(item_t));
+        for (size_t i = 0; i < n; i++) { B.arr[i].p = s->prims[i]; B.arr[i].b = prim_bounds(&s->prims[i]); }
+        int32_t root;
+        if (builder == 0) root = build_rec1(&B, 0, (int)n);
+        else if (builder == 1) root = build_rec2(&B, 0, (int)n);
+        else root = build_bottom_up(&B, (int)n);
+        for (size_t i = 0; i < n; i++) s->prims[i] = B.arr[i].p; /* hittables = sorted order, BVH.cu:174-177 */
+        free(B.arr); free(B.tmp);
+        w->kind = 0; w->root = root;
+        w->max_stack = tree_leaf_depth(s->nodes, root) + 1;
+        wb.mn = ld3(s->nodes[root].min); wb.mx = ld3(s->nodes[root].max);
+    }
+    w->n_nodes = (uint32_t)s->n_nodes; w->n_prims = (uint32_t)n; w->n_materials = (uint32_t)s->n_mats;
+    st3(w->bounds_min, wb.mn); st3(w->bounds_max, wb.mx);
+    w->nodes = s->nodes; w->prims = s->prims; w->materials = s->mats;
+}
+
+orc_scene* orc_scene_from_arrays(size_t n_prims, const orc_prim* prims, size_t n_mats, const orc_material* mats, int builder) {
+    orc_scene* s = (orc_scene*)calloc(1, sizeof(orc_scene));
+    s->prims = (orc_prim*)malloc(n_prims * sizeof(orc_prim)); memcpy(s->prims, prims, n_prims * sizeof(orc_prim)); s->n_prims = n_prims;
+    s->mats = (orc_material*)malloc(n_mats * sizeof(orc_material)); memcpy(s->mats, mats, n_mats * sizeof(orc_material)); s->n_mats = n_mats;
+    finish_scene(s, builder);
+    return s;
+}
+
+static void scene_add(orc_prim* prims, orc_material* mats, size_t* n, v3 c0, v3 c1, float r, int moving,
+                      uint32_t type, v3 albedo, float param) {
+    orc_prim* p = &prims[*n]; orc_material* m = &mats[*n];
+    st3(p->c0, c0); st3(p->c1, c1); p->radius = r; p->mat = (uint32_t)(*n) | (moving ? ORC_PRIM_MOVING : 0u);
+    st3(m->albedo, albedo); m->param = param; st3(m->albedo2, V(0, 0, 0)); m->type = type;
+    (*n)++;
+}
+
+/* SceneBook2BVH::Factory::_populate_world, Scenes.cu:219-270 (moving = 1), and
+ * the disabled SceneBook1 variant, Scenes.cu:57-115, with static Lambertians
+ * (moving = 0; the centre1 draw is still consumed so both scenes share one
+ * layout, as google_testing/test.cpp:41-51 does).  The uniforms come from the
+ * build's host stream (stream id 0x5CE9E5) instead of cuHostRND.            */
+static orc_scene* book_scene(uint64_t seed, int moving) {
+    orc_prim* prims = (orc_prim*)calloc(488, sizeof(orc_prim));
+    orc_material* mats = (orc_material*)calloc(488, sizeof(orc_material));
+    size_t n = 0;
+    rng_t g; rng_init(&g, seed, 0u, 0u, 0x5CE9E5u);
+#define RND rng_next(&g)
+    scene_add(prims, mats, &n, V(0, -1000, 0), V(0, -1000, 0), 1000.0f, 0, 0, V(0.5f, 0.5f, 0.5f), 0.0f);
+    for (int a = -11; a < 11; a++)
+        for (int b = -11; b < 11; b++) {
+            float choose_mat = RND;
+            float cx = (float)a + RND;
+            float cz = (float)b + RND;
+            v3 center = V(cx, 0.2f, cz);
+            if (choose_mat < 0.8f) {
+                float r0 = RND, r1 = RND, r2 = RND, r3 = RND, r4 = RND, r5 = RND;
+                v3 albedo = V(r0 * r1, r2 * r3, r4 * r5);
+                float rc = RND;
+                v3 center1 = add(center, V(0, rc * 0.5f, 0));
+                scene_add(prims, mats, &n, center, moving ? center1 : center, 0.2f, moving, 0, albedo, 0.0f);
+            } else if (choose_mat < 0.95f) {
+                float r0 = RND, r1 = RND, r2 = RND, r3 = RND;
+                v3 albedo = V(0.5f * (1.0f + r0), 0.5f * (1.0f + r1), 0.5f * (1.0f + r2));
+                scene_add(prims, mats, &n, center, center, 0.2f, 0, 1, albedo, 0.5f * r3);
+            } else {
+                scene_add(prims, mats, &n, center, center, 0.2f, 0, 2, V(1.0f, 1.0f, 1.0f), 1.5f);
+            }
+        }
+#undef RND
+    scene_add(prims, mats, &n, V(0, 1, 0), V(0, 1, 0), 1.0f, 0, 2, V(1.0f, 1.0f, 1.0f), 1.5f);
+    scene_add(prims, mats, &n, V(-4, 1, 0), V(-4, 1, 0), 1.0f, 0, 0, V(0.4f, 0.2f, 0.1f), 0.0f);
+    scene_add(prims, mats, &n, V(4, 1, 0), V(4, 1, 0), 1.0f, 0, 1, V(0.7f, 0.6f, 0.5f), 0.0f);
+    orc_scene* s = orc_scene_from_arrays(n, prims, n, mats, 0);
+    free(prims); free(mats);
+    return s;
+}
+orc_scene* orc_scene_book1_final(uint64_t seed) { return book_scene(seed, 0); }
+orc_scene* orc_scene_book2_moving(uint64_t seed) { return book_scene(seed, 1); }
+
+/* Book-1 three-spheres scene (config 1; not in the reference's source, layout
+ * from SURVEY.md §8d) as a HittableList.                                      */
+orc_scene* orc_scene_three_spheres(void) {
+    orc_prim prims[5]; orc_material mats[5]; size_t n = 0;
+    memset(prims, 0, sizeof(prims)); memset(mats, 0, sizeof(mats));
+    scene_add(prims, mats, &n, V(0, -100.5f, -1), V(0, -100.5f, -1), 100.0f, 0, 0, V(0.8f, 0.8f, 0.0f), 0.0f);
+    scene_add(prims, mats, &n, V(0, 0, -1.2f), V(0, 0, -1.2f), 0.5f, 0, 0, V(0.1f, 0.2f, 0.5f), 0.0f);
+    scene_add(prims, mats, &n, V(-1, 0, -1), V(-1, 0, -1), 0.5f, 0, 2, V(1.0f, 1.0f, 1.0f), 1.5f);
+    scene_add(prims, mats, &n, V(-1, 0, -1), V(-1, 0, -1), 0.4f, 0, 2, V(1.0f, 1.0f, 1.0f), 1.0f / 1.5f);
+    scene_add(prims, mats, &n, V(1, 0, -1), V(1, 0, -1), 0.5f, 0, 1, V(0.8f, 0.6f, 0.2f), 1.0f);
+    return orc_scene_from_arrays(n, prims, n, mats, 3);
+}
+void orc_scene_world(const orc_scene* s, orc_world* out) { *out = s->world; }
+void orc_scene_free(orc_scene* s) {
+    if (!s) return;
+    free(s->prims); free(s->mats); free(s->nodes); free(s);
+}

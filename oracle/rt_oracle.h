@@ -1,0 +1,137 @@
+/*
+ * rt_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the per-pixel sample loop of
+ * SuperCat908809/Ray-Tracing-v06, each function citing the reference
+ * file:line it follows (paths relative to /root/reference/).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library, and only as the checker.  The product (librt06.so) never links,
+ * loads or calls it.
+ *
+ * PIN STATUS.  The reference is CUDA C++ (cuda_runtime.h, curand_kernel.h,
+ * <<<>>> launches); none of its translation units on this path compile in
+ * this image without stand-in headers, so the reference itself is
+ * UNBUILDABLE here and it ships no golden vectors (its one gtest,
+ * google_testing/test.cpp, depends on cuRAND's host stream).  What IS pinned:
+ * the vector-math vocabulary (GLM 0.9.9.7 vendored under Libraries/include/glm
+ * and main/src/utilities/glm_utils.h) compiles with plain g++ from where it
+ * lies; oracle/ref_glm_probe.cpp builds it into oracle/_ref/ and generates
+ * tests/golden/glm_*.bin, against which every orc_glm_* function here is
+ * checked bit-for-bit.  Everything above that vocabulary (aabb::intersects,
+ * sphere test, BVH traversal, Scatter, cameras, sample_world, render_kernel)
+ * is restated by hand from the source text: PARITY UNPINNED against an
+ * executing reference.  The RNG is the build's own counter-based generator
+ * (the reference's cuRAND XORWOW streams are not reproducible offline).
+ *
+ * Arithmetic contract (shared with the HIP kernels): IEEE fp32, no FMA
+ * contraction (-ffp-contract=off), correctly rounded / and sqrtf, GLM's
+ * min/max/clamp NaN semantics, GLM's evaluation order; the single deviation
+ * is powf(1-cos,5) (cu_materials.cuh:103) computed as x2=x*x; x4=x2*x2;
+ * x5=x4*x because libm / OCML / CUDA powf differ in the last ulp.
+ */
+#ifndef RT_ORACLE_H
+#define RT_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float x, y, z; } orc_v3;
+
+/* Same byte layout as rt_bvh_node / rt_prim / rt_material / rt_camera in
+ * include/rt06.h (restated here; the oracle includes nothing of the product). */
+typedef struct { float min[3]; float max[3]; int32_t left; int32_t right; } orc_node;
+typedef struct { float c0[3]; float radius; float c1[3]; uint32_t mat; } orc_prim;
+typedef struct { float albedo[3]; float param; float albedo2[3]; uint32_t type; } orc_material;
+typedef struct {
+    uint32_t kind; int32_t root; uint32_t n_nodes, n_prims, n_materials, max_stack;
+    float bounds_min[3], bounds_max[3];
+    const orc_node* nodes; const orc_prim* prims; const orc_material* materials;
+} orc_world;
+typedef struct {
+    uint32_t type; float o[3], u[3], v[3], w[3];
+    float viewport_width, viewport_height, lens_radius, focus_dist, t0, t1;
+} orc_camera;
+
+typedef struct { float o[3]; float d[3]; float time; } orc_ray;
+
+/* instrumented counts for the algorithmic-bytes model */
+typedef struct {
+    uint64_t samples, rays, box_tests, leaf_tests, shaded_hits, rng_draws;
+    uint32_t max_stack;
+} orc_counters;
+
+/* ---- GLM vocabulary (pinned by tests/golden/glm_*.bin) ---- */
+float  orc_glm_dot(const float a[3], const float b[3]);
+void   orc_glm_cross(const float a[3], const float b[3], float out[3]);
+void   orc_glm_normalize(const float a[3], float out[3]);
+void   orc_glm_reflect(const float i[3], const float n[3], float out[3]);
+void   orc_glm_refract(const float i[3], const float n[3], float eta, float out[3]);
+void   orc_glm_mix3(const float a[3], const float b[3], float t, float out[3]);
+float  orc_glm_mix1(float a, float b, float t);
+void   orc_glm_min3(const float a[3], const float b[3], float out[3]);
+void   orc_glm_max3(const float a[3], const float b[3], float out[3]);
+float  orc_glm_compmax(const float a[3]);
+float  orc_glm_compmin(const float a[3]);
+void   orc_glm_clamp01_sqrt(const float a[3], float out[3]);
+int    orc_glm_near_zero(const float a[3]);
+float  orc_glm_length2(const float a[3]);
+void   orc_glm_lerp(const float a[3], const float b[3], float t, float out[3]);
+float  orc_glm_radians(float deg);
+
+/* ---- RNG ---- */
+void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void   orc_rng_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream,
+                        uint32_t n, float* out);
+
+/* ---- per-function batch entry points (twins of the rt_probe_* device probes) ---- */
+void orc_aabb_batch(size_t n, const float* boxes, const float* rays, const float* max_dist,
+                    int32_t* out_hit, float* out_dist);
+void orc_sphere_batch(size_t n, const float* rays, const float* spheres, float* out_t);
+int  orc_trace_batch(const orc_world* w, size_t n, const float* rays, int32_t* out_hit, float* out_t,
+                     int32_t* out_prim, float* out_normal);
+void orc_scatter_batch(uint64_t seed, size_t n, const orc_material* mats, const float* rays,
+                       const float* dist, const float* normals, const uint32_t* keys,
+                       int32_t* out_scattered, float* out_rays, float* out_atten, uint32_t* out_draws);
+void orc_camera_batch(uint64_t seed, const orc_camera* cam, size_t n, const float* st,
+                      const uint32_t* keys, float* out_rays, uint32_t* out_draws);
+int  orc_radiance_batch(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height,
+                        uint32_t max_depth, uint64_t seed, size_t n, const uint32_t* keys,
+                        float* out_radiance);
+void orc_sphere_index(const orc_camera* cam, uint32_t width, uint32_t height, size_t n_spheres,
+                      const float* spheres, int32_t* out_index);
+
+/* ---- cameras (constructors) ---- */
+void orc_camera_pinhole(const float lookfrom[3], const float lookat[3], const float up[3],
+                        float vfov, float aspect, orc_camera* out);
+void orc_camera_defocus(const float lookfrom[3], const float lookat[3], const float up[3],
+                        float vfov, float aspect, float aperture, float focus_dist, orc_camera* out);
+void orc_camera_motion(const float lookfrom[3], const float lookat[3], const float up[3],
+                       float vfov, float aspect, float t0, float t1, orc_camera* out);
+
+/* ---- the render loop (render_kernel + sample_world) ---- */
+/* Renders rows [0,height) with n_threads pthreads (dynamic row queue).
+ * out_rgba: width*height*4 floats, row 0 = bottom.  counters may be NULL.
+ * Returns 0, or 4 if the traversal stack (32, BVH.cu:17) would overflow.   */
+int orc_render(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height,
+               uint32_t spp, uint32_t max_depth, uint64_t seed, int n_threads, float* out_rgba,
+               orc_counters* counters);
+
+/* ---- scene generation + BVH build (host side of the path, a15/a16) ---- */
+typedef struct orc_scene orc_scene;
+orc_scene* orc_scene_book1_final(uint64_t seed);
+orc_scene* orc_scene_book2_moving(uint64_t seed);
+orc_scene* orc_scene_three_spheres(void);
+/* generic: build from caller arrays; builder 0 = top-down median, 1 = binned SAH,
+ * 2 = bottom-up, 3 = HittableList                                              */
+orc_scene* orc_scene_from_arrays(size_t n_prims, const orc_prim* prims, size_t n_mats,
+                                 const orc_material* mats, int builder);
+void orc_scene_world(const orc_scene* s, orc_world* out);
+void orc_scene_free(orc_scene* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
