@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — Msamples/s of the per-pixel sample loop on the Book-1 final scene (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one Render() of the whole 1200x800x500-spp frame (4.8e8 pixel-samples) with the flat scene
+already resident in HBM: N == 1 launches the kernel(s) into the row-major framebuffer; N > 1 tile-shards
+the frame over the ranks (one process per GPU), each rank renders its shard, ONE RCCL gather moves the
+shards to rank 0 over xGMI and a de-interleave kernel assembles the image.  Total work is fixed as N
+grows ("strong" scaling).  Rank 0 prints one JSON line.
+
+`roofline` prices the dominant kernel against HBM with SURVEY.md §8(d)'s ALGORITHMIC bytes per sample
+(32 B per box test + 16 B per sphere test + 16 B per shaded hit + 16/spp B of framebuffer), the counts
+measured by the instrumented CPU oracle on the same scene and seed.  `cpu_baseline` times that oracle (a
+CPU port of the loop — the reference has no CPU renderer) on the host cores, on a bounded spp.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as G  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--seed", type=int, default=1984)
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
+    """cpu_baseline + algorithmic counts + parity sample, rank 0 at N == 1 only.  The oracle is the checker
+    and the timed baseline here; it is never on the product path."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    cores = len(os.sched_getaffinity(0))
+    W, H = args.width, args.height
+    oscene = O.Scene.book1_final(args.seed)
+    ocam = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    # calibrate on 1 spp, then size the sample for ~cpu_seconds of wall time
+    t = time.perf_counter()
+    O.render(oscene.world, ocam, W, H, 1, args.depth, args.seed, threads=cores)
+    t1 = time.perf_counter() - t
+    spp = int(max(1, min(args.spp, args.cpu_seconds / max(t1, 1e-3))))
+    t = time.perf_counter()
+    ref, cnt = O.render(oscene.world, ocam, W, H, spp, args.depth, args.seed, threads=cores)
+    dt = time.perf_counter() - t
+    n = float(cnt.samples)
+    counts = {"box_tests": cnt.box_tests / n, "leaf_tests": cnt.leaf_tests / n, "shaded_hits": cnt.shaded_hits / n,
+              "rays": cnt.rays / n, "rng_draws": cnt.rng_draws / n}
+    base = {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{W}x{H}x{spp}spp Book-1 final, depth {args.depth}, seed {args.seed}, {dt:.1f}s wall, "
+                      f"gcc -O2 -ffp-contract=off, pthreads over rows"}
+    parity = None
+    if gpu_image_fn is not None:
+        img = gpu_image_fn(spp)
+        d = np.abs(img[..., :3] - ref[..., :3])
+        parity = {"max_abs_delta": float(np.nanmax(d)), "mean_abs_delta": float(np.nanmean(d)),
+                  "tolerance": 1e-3, "sample": f"{W}x{H}x{spp}spp GPU vs CPU oracle, same seed"}
+    return base, counts, parity
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    pkg = G.load_package()
+    W, H, spp = args.width, args.height, args.spp
+    scene = pkg.Scene.book1_final(args.seed)
+    cam = pkg.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    world = scene.getWorldPtr()
+    r = pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank,
+                                  rank=rank, world_size=world_size, variant=args.variant)
+    stream = torch.cuda.current_stream()
+    image = torch.zeros(H * W * 4, dtype=torch.float32, device=dev) if rank == 0 else None
+    if world_size > 1:
+        shard = torch.zeros(r.shard_floats(), dtype=torch.float32, device=dev)
+        gathered = torch.zeros(r.shard_floats() * world_size, dtype=torch.float32, device=dev) if rank == 0 else None
+        glist = list(gathered.chunk(world_size)) if rank == 0 else None
+
+    kernel_events = []
+
+    def step(record):
+        e0 = e1 = None
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        if world_size == 1:
+            r.render_async(stream.cuda_stream, image.data_ptr())
+        else:
+            r.render_async(stream.cuda_stream, shard.data_ptr())
+        if record:
+            e1.record(stream)
+            kernel_events.append((e0, e1))
+        if world_size > 1:
+            dist.gather(shard, glist, dst=0)  # the single frame-end exchange (RCCL over xGMI)
+            if rank == 0:
+                r.assemble(gathered.data_ptr(), image.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_events])) if kernel_events else float("nan")
+
+    total_samples = float(W) * H * spp
+    out = None
+    if rank == 0:
+        base = counts = parity = None
+        if world_size == 1 and args.cpu_seconds > 0:
+            def gpu_image(spp_small):
+                rr = pkg.Renderer.MakeRenderer(W, H, spp_small, args.depth, cam, world, seed=args.seed, device=local_rank,
+                                               variant=args.variant)
+                rr.Render()
+                img = rr.DownloadRenderbuffer()
+                rr.close()
+                return img
+            base, counts, parity = cpu_leg(args, pkg, scene, cam, None if args.no_parity else gpu_image)
+        value = total_samples * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Msamples/sec (WxHxspp) on Book-1 final scene",
+            "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Book-1 final random-spheres scene (488 spheres, 975-node BVH), {W}x{H}, {spp} spp, "
+                                   f"max_depth {args.depth}, seed {args.seed}, DefocusBlurCamera vfov 20 aperture 0.1",
+                       "parallelism": f"tile-shard x{world_size} + 1 RCCL gather" if world_size > 1 else "single GPU",
+                       "kernel_variant": args.variant},
+            "kernel_ms_per_step_rank0": round(kernel_ms, 3),
+        }
+        if counts is not None:
+            bytes_per_sample = 32.0 * counts["box_tests"] + 16.0 * counts["leaf_tests"] + 16.0 * counts["shaded_hits"] + 16.0 / spp
+            launch_samples = total_samples / world_size
+            achieved = bytes_per_sample * launch_samples / (kernel_ms * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "kernel": "render kernel", "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+                               "counts_per_sample": {k: round(v, 3) for k, v in counts.items()}}
+            out["cpu_baseline"] = base
+            if parity is not None:
+                out["parity"] = parity
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -595,6 +595,21 @@ int orc_radiance_batch(const orc_world* w, const orc_camera* cam, uint32_t width
         st3(out_radiance + 3 * i, one_sample(w, cam, width, height, max_depth, seed, keys[2 * i], keys[2 * i + 1], &cnt, &err));
     return err;
 }
+/* render_kernel for a list of pixels (full spp loop, mean, clamp, gamma): lets a test check a sparse
+ * sample of a full-size frame without rendering all of it on the CPU. */
+int orc_render_pixels(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height, uint32_t spp,
+                      uint32_t max_depth, uint64_t seed, size_t n, const uint32_t* gids, float* out_rgba) {
+    orc_counters cnt; memset(&cnt, 0, sizeof(cnt));
+    int err = 0;
+    float* tmp = (float*)malloc((size_t)width * height * 4 * sizeof(float));
+    for (size_t i = 0; i < n; i++) {
+        uint32_t gid = gids[i];
+        render_pixel(w, cam, width, height, spp, max_depth, seed, gid % width, gid / width, tmp, &cnt, &err);
+        memcpy(out_rgba + 4 * i, tmp + (size_t)gid * 4, 4 * sizeof(float));
+    }
+    free(tmp);
+    return err;
+}
 /* SphereTest::_pixel_ground_truth, google_testing/test.cpp:87-106 */
 void orc_sphere_index(const orc_camera* cam, uint32_t width, uint32_t height, size_t n_spheres, const float* spheres, int32_t* out_index) {
     for (uint32_t y = 0; y < height; y++)

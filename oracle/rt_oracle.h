@@ -119,6 +119,9 @@ int orc_render(const orc_world* w, const orc_camera* cam, uint32_t width, uint32
                uint32_t spp, uint32_t max_depth, uint64_t seed, int n_threads, float* out_rgba,
                orc_counters* counters);
 
+int orc_render_pixels(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height, uint32_t spp,
+                      uint32_t max_depth, uint64_t seed, size_t n, const uint32_t* gids, float* out_rgba);
+
 /* ---- scene generation + BVH build (host side of the path, a15/a16) ---- */
 typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_book1_final(uint64_t seed);

@@ -1,0 +1,275 @@
+"""Python view of the reference-shaped host API, over the C ABI (used by tests/ and bench.py).
+
+Names follow the reference: Sphere / MovingSphere, material descriptors, SphereHandle-style adders,
+BVH_Handle.Factory builders, the three cameras, and Renderer.MakeRenderer / Render /
+DownloadRenderbuffer (main/src/Renderer.h:38-46).  The C++ twin of this file is include/rt06/*.hpp.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import Camera, RenderConfig, WorldFlat, check, lib, v3
+
+
+def PinholeCamera(lookfrom, lookat, up, vfov, aspect_ratio):
+    """PinholeCamera ctor, rt_engine/shaders/cu_Cameras.cuh:16-25."""
+    c = Camera()
+    check(lib().rt_camera_pinhole(v3(lookfrom), v3(lookat), v3(up), vfov, aspect_ratio, C.byref(c)))
+    return c
+
+
+def DefocusBlurCamera(lookfrom, lookat, up, vfov, aspect_ratio, aperture, focus_dist):
+    """DefocusBlurCamera ctor, cu_Cameras.cuh:40-52."""
+    c = Camera()
+    check(lib().rt_camera_defocus(v3(lookfrom), v3(lookat), v3(up), vfov, aspect_ratio, aperture, focus_dist, C.byref(c)))
+    return c
+
+
+def MotionBlurCamera(lookfrom, lookat, up, vfov, aspect_ratio, time0, time1):
+    """MotionBlurCamera ctor, cu_Cameras.cuh:73-85."""
+    c = Camera()
+    check(lib().rt_camera_motion(v3(lookfrom), v3(lookat), v3(up), vfov, aspect_ratio, time0, time1, C.byref(c)))
+    return c
+
+
+class Scene:
+    """Host scene: what SphereHandle / newOnDevice<Material> / BVH_Handle::Factory / HittableList /
+    bvh_node build in the reference, kept as flat arrays."""
+
+    def __init__(self, handle=None):
+        if handle is None:
+            h = C.c_void_p()
+            check(lib().rt_scene_create(C.byref(h)))
+            handle = h
+        self.h = handle
+
+    # --- prefab scenes (SceneBook2BVH::Factory::MakeScene and friends) ---
+    @classmethod
+    def book1_final(cls, seed=1984):
+        h = C.c_void_p()
+        check(lib().rt_scene_book1_final(seed, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def book2_moving(cls, seed=1984):
+        h = C.c_void_p()
+        check(lib().rt_scene_book2_moving(seed, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def three_spheres(cls):
+        h = C.c_void_p()
+        check(lib().rt_scene_three_spheres(C.byref(h)))
+        return cls(h)
+
+    # --- vocabulary ---
+    def add_material(self, mtype, albedo, param=0.0, albedo2=None):
+        out = C.c_int32()
+        a2 = v3(albedo2) if albedo2 is not None else None
+        check(lib().rt_scene_add_material(self.h, mtype, v3(albedo), param, a2, C.byref(out)))
+        return out.value
+
+    def Lambertian(self, albedo):
+        return self.add_material(capi.MAT_LAMBERTIAN, albedo)
+
+    def Metal(self, albedo, fuzz):
+        return self.add_material(capi.MAT_METAL, albedo, fuzz)
+
+    def Dielectric(self, albedo, ior):
+        return self.add_material(capi.MAT_DIELECTRIC, albedo, ior)
+
+    def LambertianTexture(self, c1, c2, scale):
+        return self.add_material(capi.MAT_LAMBERTIAN_CHECKER, c1, np.float32(1.0) / np.float32(scale), c2)
+
+    def MakeSphere(self, center, radius, mat):
+        out = C.c_int32()
+        check(lib().rt_scene_add_sphere(self.h, v3(center), radius, mat, C.byref(out)))
+        return out.value
+
+    def MakeMovingSphere(self, c0, c1, radius, mat):
+        out = C.c_int32()
+        check(lib().rt_scene_add_moving_sphere(self.h, v3(c0), v3(c1), radius, mat, C.byref(out)))
+        return out.value
+
+    def prim_bounds(self, prim):
+        mn, mx = capi.vec3(), capi.vec3()
+        check(lib().rt_scene_prim_bounds(self.h, prim, mn, mx))
+        return np.array(mn[:], dtype=np.float32), np.array(mx[:], dtype=np.float32)
+
+    def BuildBVH_TopDown(self):
+        check(lib().rt_scene_build_bvh_topdown(self.h))
+        return self
+
+    def BuildBVH_SAH(self):
+        check(lib().rt_scene_build_bvh_sah(self.h))
+        return self
+
+    def BuildBVH_BottomUp(self):
+        check(lib().rt_scene_build_bvh_bottomup(self.h))
+        return self
+
+    def MakeHittableList(self):
+        check(lib().rt_scene_set_world_list(self.h))
+        return self
+
+    def bvh_node(self, left_ref, right_ref, bounds=None):
+        out = C.c_int32()
+        if bounds is None:
+            check(lib().rt_scene_add_bvh_node(self.h, left_ref, right_ref, None, None, C.byref(out)))
+        else:
+            mn, mx = v3(bounds[0]), v3(bounds[1])
+            check(lib().rt_scene_add_bvh_node(self.h, left_ref, right_ref, mn, mx, C.byref(out)))
+        return out.value
+
+    @staticmethod
+    def prim_ref(prim):
+        return -prim - 1
+
+    def set_world_node_tree(self, root_ref):
+        check(lib().rt_scene_set_world_node_tree(self.h, root_ref))
+        return self
+
+    # --- flat view ---
+    def getWorldPtr(self):
+        w = WorldFlat()
+        check(lib().rt_scene_get_flat(self.h, C.byref(w)))
+        return w
+
+    def _arr(self, ptr, n, dt):
+        if n == 0 or not ptr:
+            return np.zeros(0, dtype=dt)
+        buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dt).copy()
+
+    def arrays(self):
+        w = self.getWorldPtr()
+        return (self._arr(w.nodes, w.n_nodes, capi.NODE_DT), self._arr(w.prims, w.n_prims, capi.PRIM_DT),
+                self._arr(w.materials, w.n_materials, capi.MAT_DT))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().rt_scene_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Renderer:
+    """Renderer (main/src/Renderer.h:12-47) over the C ABI."""
+
+    def __init__(self, handle, cfg):
+        self.h = handle
+        self.cfg = cfg
+
+    @classmethod
+    def MakeRenderer(cls, render_width, render_height, samples_per_pixel, max_depth, cam, world,
+                     seed=1984, device=0, rank=0, world_size=1, variant=0):
+        cfg = RenderConfig(render_width, render_height, samples_per_pixel, max_depth, seed, device, rank, world_size, variant)
+        h = C.c_void_p()
+        check(lib().rt_renderer_create(C.byref(cfg), C.byref(cam), C.byref(world), C.byref(h)))
+        return cls(h, cfg)
+
+    def Render(self):
+        check(lib().rt_renderer_render(self.h))
+
+    def render_async(self, stream=None, d_out=None):
+        check(lib().rt_renderer_render_async(self.h, C.c_void_p(stream or 0), C.c_void_p(d_out or 0)))
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        check(lib().rt_renderer_last_kernel_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    def DownloadRenderbuffer(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), dtype=np.float32)
+        check(lib().rt_renderer_download(self.h, out, out.size))
+        return out
+
+    def shard_floats(self):
+        n = C.c_size_t()
+        check(lib().rt_renderer_shard_floats(self.h, C.byref(n)))
+        return n.value
+
+    def assemble(self, d_gathered, d_image, stream=None):
+        check(lib().rt_renderer_assemble(self.h, C.c_void_p(d_gathered), C.c_void_p(d_image), C.c_void_p(stream or 0)))
+
+    def close(self):
+        if self.h:
+            lib().rt_renderer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --- device probes -------------------------------------------------------------------------------
+def probe_aabb(boxes, rays, max_dist, device=0):
+    n = len(boxes)
+    hit = np.zeros(n, np.int32); dist = np.zeros(n, np.float32)
+    check(lib().rt_probe_aabb(device, n, np.ascontiguousarray(boxes, np.float32), np.ascontiguousarray(rays, np.float32),
+                              np.ascontiguousarray(max_dist, np.float32), hit, dist))
+    return hit, dist
+
+
+def probe_sphere(rays, spheres, device=0):
+    n = len(rays)
+    t = np.zeros(n, np.float32)
+    check(lib().rt_probe_sphere(device, n, np.ascontiguousarray(rays, np.float32), np.ascontiguousarray(spheres, np.float32), t))
+    return t
+
+
+def probe_trace(world, rays, device=0):
+    n = len(rays)
+    hit = np.zeros(n, np.int32); t = np.zeros(n, np.float32); prim = np.zeros(n, np.int32); nrm = np.zeros((n, 3), np.float32)
+    check(lib().rt_probe_trace(device, C.byref(world), n, np.ascontiguousarray(rays, np.float32), hit, t, prim, nrm))
+    return hit, t, prim, nrm
+
+
+def probe_scatter(seed, mats, rays, dist, normals, keys, device=0):
+    n = len(rays)
+    mats = np.ascontiguousarray(mats, dtype=capi.MAT_DT)
+    sc = np.zeros(n, np.int32); orays = np.zeros((n, 7), np.float32); att = np.zeros((n, 3), np.float32); draws = np.zeros(n, np.uint32)
+    check(lib().rt_probe_scatter(device, seed, n, mats.ctypes.data, np.ascontiguousarray(rays, np.float32),
+                                 np.ascontiguousarray(dist, np.float32), np.ascontiguousarray(normals, np.float32),
+                                 np.ascontiguousarray(keys, np.uint32), sc, orays, att, draws))
+    return sc, orays, att, draws
+
+
+def probe_camera(seed, cam, st, keys, device=0):
+    n = len(st)
+    orays = np.zeros((n, 7), np.float32); draws = np.zeros(n, np.uint32)
+    check(lib().rt_probe_camera(device, seed, C.byref(cam), n, np.ascontiguousarray(st, np.float32),
+                                np.ascontiguousarray(keys, np.uint32), orays, draws))
+    return orays, draws
+
+
+def probe_radiance(cfg, cam, world, keys):
+    n = len(keys)
+    out = np.zeros((n, 3), np.float32)
+    check(lib().rt_probe_radiance(C.byref(cfg), C.byref(cam), C.byref(world), n, np.ascontiguousarray(keys, np.uint32), out))
+    return out
+
+
+def probe_sphere_index(cam, width, height, spheres, device=0):
+    out = np.zeros(width * height, np.int32)
+    spheres = np.ascontiguousarray(spheres, np.float32)
+    check(lib().rt_probe_sphere_index(device, C.byref(cam), width, height, len(spheres), spheres, out))
+    return out.reshape(height, width)
+
+
+def probe_rng(seed, keys, n_draws, device=0):
+    n = len(keys)
+    out = np.zeros((n, n_draws), np.float32)
+    check(lib().rt_probe_rng(device, seed, n, np.ascontiguousarray(keys, np.uint32), n_draws, out))
+    return out
+
+
+def device_count():
+    n = C.c_int()
+    check(lib().rt_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,139 @@
+"""ctypes binding of librt06.so (the C ABI declared in include/rt06.h).
+
+The product path is the HIP library and nothing else: if librt06.so is missing or fails to load this
+raises — there is no CPU fallback and nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "librt06.so")
+
+RT_OK = 0
+RT_PRIM_MOVING = 0x80000000
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LAMBERTIAN_CHECKER = 0, 1, 2, 3
+WORLD_BVH, WORLD_LIST, WORLD_NODE_TREE = 0, 1, 2
+CAM_PINHOLE, CAM_DEFOCUS, CAM_MOTION = 0, 1, 2
+
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+vec3 = C.c_float * 3
+
+NODE_DT = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("right", "<i4")])
+PRIM_DT = np.dtype([("c0", "<f4", 3), ("radius", "<f4"), ("c1", "<f4", 3), ("mat", "<u4")])
+MAT_DT = np.dtype([("albedo", "<f4", 3), ("param", "<f4"), ("albedo2", "<f4", 3), ("type", "<u4")])
+
+
+class WorldFlat(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("root", C.c_int32), ("n_nodes", C.c_uint32), ("n_prims", C.c_uint32),
+                ("n_materials", C.c_uint32), ("max_stack", C.c_uint32),
+                ("bounds_min", vec3), ("bounds_max", vec3),
+                ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("o", vec3), ("u", vec3), ("v", vec3), ("w", vec3),
+                ("viewport_width", C.c_float), ("viewport_height", C.c_float),
+                ("lens_radius", C.c_float), ("focus_dist", C.c_float), ("t0", C.c_float), ("t1", C.c_float)]
+
+
+class RenderConfig(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_per_pixel", C.c_uint32),
+                ("max_depth", C.c_uint32), ("seed", C.c_uint64), ("device", C.c_int32),
+                ("rank", C.c_uint32), ("world_size", C.c_uint32), ("variant", C.c_uint32)]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rt06 error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/rt06.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "rt_last_error", "rt_camera_pinhole", "rt_camera_defocus", "rt_camera_motion",
+    "rt_scene_create", "rt_scene_destroy", "rt_scene_add_material", "rt_scene_add_sphere",
+    "rt_scene_add_moving_sphere", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
+    "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list", "rt_scene_add_bvh_node",
+    "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
+    "rt_scene_three_spheres", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
+    "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_download", "rt_renderer_shard_floats",
+    "rt_renderer_assemble", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
+    "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_device_count", "rt_version",
+]
+
+_lib = None
+
+
+def build_native(force=False):
+    """Compile librt06.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", CSRC_DIR]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path.")
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_version.restype = C.c_char_p
+    L.rt_camera_pinhole.argtypes = [vec3, vec3, vec3, C.c_float, C.c_float, P(Camera)]
+    L.rt_camera_defocus.argtypes = [vec3, vec3, vec3, C.c_float, C.c_float, C.c_float, C.c_float, P(Camera)]
+    L.rt_camera_motion.argtypes = [vec3, vec3, vec3, C.c_float, C.c_float, C.c_float, C.c_float, P(Camera)]
+    L.rt_scene_create.argtypes = [P(C.c_void_p)]
+    L.rt_scene_destroy.argtypes = [C.c_void_p]
+    L.rt_scene_destroy.restype = None
+    L.rt_scene_add_material.argtypes = [C.c_void_p, C.c_uint32, vec3, C.c_float, C.c_void_p, P(C.c_int32)]
+    L.rt_scene_add_sphere.argtypes = [C.c_void_p, vec3, C.c_float, C.c_int32, P(C.c_int32)]
+    L.rt_scene_add_moving_sphere.argtypes = [C.c_void_p, vec3, vec3, C.c_float, C.c_int32, P(C.c_int32)]
+    L.rt_scene_prim_bounds.argtypes = [C.c_void_p, C.c_int32, vec3, vec3]
+    for n in ("rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah", "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list"):
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.rt_scene_add_bvh_node.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, P(C.c_int32)]
+    L.rt_scene_set_world_node_tree.argtypes = [C.c_void_p, C.c_int32]
+    L.rt_scene_get_flat.argtypes = [C.c_void_p, P(WorldFlat)]
+    L.rt_scene_book1_final.argtypes = [C.c_uint64, P(C.c_void_p)]
+    L.rt_scene_book2_moving.argtypes = [C.c_uint64, P(C.c_void_p)]
+    L.rt_scene_three_spheres.argtypes = [P(C.c_void_p)]
+    L.rt_renderer_create.argtypes = [P(RenderConfig), P(Camera), P(WorldFlat), P(C.c_void_p)]
+    L.rt_renderer_destroy.argtypes = [C.c_void_p]
+    L.rt_renderer_destroy.restype = None
+    L.rt_renderer_render.argtypes = [C.c_void_p]
+    L.rt_renderer_render_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_renderer_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    L.rt_renderer_download.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    L.rt_renderer_shard_floats.argtypes = [C.c_void_p, P(C.c_size_t)]
+    L.rt_renderer_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.rt_probe_aabb.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p, i32p, f32p]
+    L.rt_probe_sphere.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
+    L.rt_probe_trace.argtypes = [C.c_int, P(WorldFlat), C.c_size_t, f32p, i32p, f32p, i32p, f32p]
+    L.rt_probe_scatter.argtypes = [C.c_int, C.c_uint64, C.c_size_t, C.c_void_p, f32p, f32p, f32p, u32p, i32p, f32p, f32p, u32p]
+    L.rt_probe_camera.argtypes = [C.c_int, C.c_uint64, P(Camera), C.c_size_t, f32p, u32p, f32p, u32p]
+    L.rt_probe_radiance.argtypes = [P(RenderConfig), P(Camera), P(WorldFlat), C.c_size_t, u32p, f32p]
+    L.rt_probe_sphere_index.argtypes = [C.c_int, P(Camera), C.c_uint32, C.c_uint32, C.c_size_t, f32p, i32p]
+    L.rt_probe_rng.argtypes = [C.c_int, C.c_uint64, C.c_size_t, u32p, C.c_uint32, f32p]
+    L.rt_device_count.argtypes = [P(C.c_int)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_last_error().decode("utf-8", "replace"))
+
+
+def v3(a):
+    return vec3(*[float(x) for x in a])

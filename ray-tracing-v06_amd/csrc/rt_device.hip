@@ -1,0 +1,469 @@
+// rt_device.hip — HIP kernels (gfx950) and the device half of the C ABI: Renderer + probes.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "rt06.h"
+#include "rt_device_funcs.hpp"
+#include "rt_internal.hpp"
+#include "rt_math.hpp"
+#include "rt_render_kernels.hpp"
+
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            return rt_fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// small RAII helpers (host side)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        bytes = n;
+        return hipMalloc(&p, n ? n : 1);
+    }
+    hipError_t upload(const void* src, size_t n) {
+        hipError_t e = alloc(n);
+        if (e != hipSuccess) return e;
+        return n ? hipMemcpy(p, src, n, hipMemcpyHostToDevice) : hipSuccess;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct DeviceScene {
+    DevBuf nodes, prims, mats;
+    DeviceWorld dw{};
+    int upload(const rt_world_flat* w) {
+        if (!w) return rt_fail(RT_ERR_INVALID, "null world");
+        if (w->kind > RT_WORLD_NODE_TREE) return rt_fail(RT_ERR_INVALID, "unknown world kind %u", w->kind);
+        if (w->n_prims == 0 || !w->prims) return rt_fail(RT_ERR_INVALID, "world has no primitives");
+        if (w->n_materials == 0 || !w->materials) return rt_fail(RT_ERR_INVALID, "world has no materials");
+        if (w->kind != RT_WORLD_LIST && (w->n_nodes == 0 || !w->nodes)) return rt_fail(RT_ERR_INVALID, "BVH world has no nodes");
+        if (w->max_stack > RT_MAX_STACK) return rt_fail(RT_ERR_STACK, "world needs a %u-entry traversal stack; limit %d", w->max_stack, RT_MAX_STACK);
+        // validate every index the kernels will follow: a bad index is a GPU fault, not an error code
+        for (uint32_t i = 0; i < w->n_prims; i++)
+            if ((w->prims[i].mat & ~RT_PRIM_MOVING) >= w->n_materials) return rt_fail(RT_ERR_INVALID, "primitive %u: material index out of range", i);
+        for (uint32_t i = 0; i < w->n_materials; i++)
+            if (w->materials[i].type > RT_MAT_LAMBERTIAN_CHECKER) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
+        if (w->kind == RT_WORLD_BVH) {
+            if (w->root < 0 || (uint32_t)w->root >= w->n_nodes) return rt_fail(RT_ERR_INVALID, "BVH root out of range");
+            for (uint32_t i = 0; i < w->n_nodes; i++) {
+                const rt_bvh_node& n = w->nodes[i];
+                if (n.left == -1) {
+                    if (n.right < 0 || (uint32_t)n.right >= w->n_prims) return rt_fail(RT_ERR_INVALID, "BVH leaf %u: primitive index out of range", i);
+                } else if (n.left < 0 || (uint32_t)n.left >= w->n_nodes || n.right < 0 || (uint32_t)n.right >= w->n_nodes || (uint32_t)n.left == i || (uint32_t)n.right == i)
+                    return rt_fail(RT_ERR_INVALID, "BVH node %u: child index out of range", i);
+            }
+        } else if (w->kind == RT_WORLD_NODE_TREE) {
+            auto ok = [&](int32_t r) { return r >= 0 ? (uint32_t)r < w->n_nodes : (uint32_t)(-r - 1) < w->n_prims; };
+            if (!ok(w->root)) return rt_fail(RT_ERR_INVALID, "bvh_node tree root out of range");
+            for (uint32_t i = 0; i < w->n_nodes; i++)
+                if (!ok(w->nodes[i].left) || !ok(w->nodes[i].right) || w->nodes[i].left == (int32_t)i || w->nodes[i].right == (int32_t)i)
+                    return rt_fail(RT_ERR_INVALID, "bvh_node %u: child reference out of range", i);
+        }
+        HIP_TRY(nodes.upload(w->nodes, sizeof(rt_bvh_node) * (size_t)w->n_nodes));
+        HIP_TRY(prims.upload(w->prims, sizeof(rt_prim) * (size_t)w->n_prims));
+        HIP_TRY(mats.upload(w->materials, sizeof(rt_material) * (size_t)w->n_materials));
+        dw.kind = w->kind; dw.root = w->root;
+        dw.n_nodes = w->n_nodes; dw.n_prims = w->n_prims; dw.n_mats = w->n_materials;
+        dw.bmin = mk3(w->bounds_min[0], w->bounds_min[1], w->bounds_min[2]);
+        dw.bmax = mk3(w->bounds_max[0], w->bounds_max[1], w->bounds_max[2]);
+        dw.nodes = nodes.as<rt_bvh_node>(); dw.prims = prims.as<rt_prim>(); dw.mats = mats.as<rt_material>();
+        return RT_OK;
+    }
+};
+
+int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return rt_fail(RT_ERR_NO_DEVICE, "no HIP device available: the HIP path is required, there is no CPU fallback");
+    if (device < 0 || device >= n) return rt_fail(RT_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return RT_OK;
+}
+}  // namespace
+
+extern "C" int rt_device_count(int* out) {
+    if (!out) return rt_fail(RT_ERR_INVALID, "rt_device_count: null out");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *out = n;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Renderer
+// ---------------------------------------------------------------------------------------------
+struct rt_renderer {
+    rt_render_config cfg{};
+    rt_camera cam{};
+    DeviceScene scene;
+    TileMap tm{};
+    DevBuf fb;
+    DevBuf work_counter;
+    size_t shard_floats = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    ~rt_renderer() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+extern "C" int rt_renderer_create(const rt_render_config* cfg, const rt_camera* cam, const rt_world_flat* world, rt_renderer** out) {
+    if (!cfg || !cam || !world || !out) return rt_fail(RT_ERR_INVALID, "rt_renderer_create: null argument");
+    if (cfg->width == 0 || cfg->height == 0 || cfg->samples_per_pixel == 0)
+        return rt_fail(RT_ERR_INVALID, "rt_renderer_create: width, height and samples_per_pixel must be > 0");
+    if ((uint64_t)cfg->width * cfg->height > 0x7fffffffull) return rt_fail(RT_ERR_INVALID, "rt_renderer_create: image too large");
+    if (cfg->world_size == 0 || cfg->rank >= cfg->world_size) return rt_fail(RT_ERR_INVALID, "rt_renderer_create: bad rank %u / world_size %u", cfg->rank, cfg->world_size);
+    if (cam->type > RT_CAM_MOTION) return rt_fail(RT_ERR_INVALID, "rt_renderer_create: unknown camera type %u", cam->type);
+    int rc = select_device(cfg->device);
+    if (rc != RT_OK) return rc;
+    rt_renderer* r = new rt_renderer();
+    r->cfg = *cfg;
+    r->cam = *cam;
+    rc = r->scene.upload(world);
+    if (rc != RT_OK) { delete r; return rc; }
+    TileMap& tm = r->tm;
+    tm.width = cfg->width; tm.height = cfg->height;
+    tm.tiles_x = (cfg->width + RT_TILE - 1) / RT_TILE;
+    uint32_t tiles_y = (cfg->height + RT_TILE - 1) / RT_TILE;
+    tm.n_tiles = tm.tiles_x * tiles_y;
+    tm.rank = cfg->rank; tm.world_size = cfg->world_size;
+    tm.n_local_tiles = (tm.n_tiles + cfg->world_size - 1) / cfg->world_size;
+    tm.direct = cfg->world_size == 1 ? 1u : 0u;
+    r->shard_floats = (size_t)tm.n_local_tiles * RT_TILE * RT_TILE * 4;
+    size_t fb_floats = tm.direct ? (size_t)cfg->width * cfg->height * 4 : r->shard_floats;
+    hipError_t e = r->fb.alloc(fb_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(r->fb.p, 0, fb_floats * sizeof(float));
+    if (e == hipSuccess) e = r->work_counter.alloc(256);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&r->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&r->ev1);
+    if (e != hipSuccess) { delete r; return rt_fail(RT_ERR_HIP, "rt_renderer_create: %s", hipGetErrorString(e)); }
+    *out = r;
+    return RT_OK;
+}
+
+extern "C" void rt_renderer_destroy(rt_renderer* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->cfg.device);
+    delete r;
+}
+
+extern "C" int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float* d_out) {
+    if (!r) return rt_fail(RT_ERR_INVALID, "rt_renderer_render_async: null renderer");
+    HIP_TRY(hipSetDevice(r->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : r->stream;
+    RenderParams p;
+    p.width = r->cfg.width; p.height = r->cfg.height;
+    p.spp = r->cfg.samples_per_pixel; p.max_depth = r->cfg.max_depth;
+    p.seed = r->cfg.seed;
+    p.cam = r->cam;
+    p.world = r->scene.dw;
+    p.tm = r->tm;
+    p.out = d_out ? d_out : r->fb.as<float>();
+    p.work_counter = r->work_counter.as<uint32_t>();
+    HIP_TRY(hipEventRecord(r->ev0, st));
+    int rc = launch_render(p, r->cfg.variant, st);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(r->ev1, st));
+    r->timed = true;
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_render(rt_renderer* r) {
+    int rc = rt_renderer_render_async(r, nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms) {
+    if (!r || !out_ms) return rt_fail(RT_ERR_INVALID, "rt_renderer_last_kernel_ms: null argument");
+    if (!r->timed) return rt_fail(RT_ERR_INVALID, "rt_renderer_last_kernel_ms: nothing rendered yet");
+    HIP_TRY(hipSetDevice(r->cfg.device));
+    HIP_TRY(hipEventSynchronize(r->ev1));
+    HIP_TRY(hipEventElapsedTime(out_ms, r->ev0, r->ev1));
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_download(rt_renderer* r, float* host_rgba, size_t n_floats) {
+    if (!r || !host_rgba) return rt_fail(RT_ERR_INVALID, "rt_renderer_download: null argument");
+    if (r->cfg.world_size != 1) return rt_fail(RT_ERR_INVALID, "rt_renderer_download: renderer holds one shard of %u; gather and rt_renderer_assemble first", r->cfg.world_size);
+    size_t need = (size_t)r->cfg.width * r->cfg.height * 4;
+    if (n_floats != need) return rt_fail(RT_ERR_INVALID, "rt_renderer_download: buffer holds %zu floats, image needs %zu", n_floats, need);
+    HIP_TRY(hipSetDevice(r->cfg.device));
+    HIP_TRY(hipStreamSynchronize(r->stream));
+    HIP_TRY(hipMemcpy(host_rgba, r->fb.p, need * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_shard_floats(const rt_renderer* r, size_t* out) {
+    if (!r || !out) return rt_fail(RT_ERR_INVALID, "rt_renderer_shard_floats: null argument");
+    *out = r->shard_floats;
+    return RT_OK;
+}
+
+// de-interleave the gathered shards (rank-major, tile-major inside a shard) into the row-major image
+__global__ void assemble_kernel(const float4* __restrict__ gathered, float4* __restrict__ image, TileMap tm, uint32_t shard_pixels) {
+    uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= tm.width * tm.height) return;
+    uint32_t x = gid % tm.width, y = gid / tm.width;
+    uint32_t gt = (y / RT_TILE) * tm.tiles_x + (x / RT_TILE);
+    uint32_t rank = gt % tm.world_size, tl = gt / tm.world_size;
+    uint32_t p = (y % RT_TILE) * RT_TILE + (x % RT_TILE);
+    image[gid] = gathered[(size_t)rank * shard_pixels + (size_t)tl * (RT_TILE * RT_TILE) + p];
+}
+
+extern "C" int rt_renderer_assemble(rt_renderer* r, const float* d_gathered, float* d_image, void* hip_stream) {
+    if (!r || !d_gathered || !d_image) return rt_fail(RT_ERR_INVALID, "rt_renderer_assemble: null argument");
+    HIP_TRY(hipSetDevice(r->cfg.device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : r->stream;
+    uint32_t n = r->cfg.width * r->cfg.height;
+    assemble_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float4*)d_gathered, (float4*)d_image, r->tm,
+                                                      (uint32_t)(r->shard_floats / 4));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// probes
+// ---------------------------------------------------------------------------------------------
+__global__ void probe_aabb_kernel(size_t n, const float* boxes, const float* rays, const float* maxd, int32_t* hit, float* dist) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = ld3(rays + 6 * i); r.d = ld3(rays + 6 * i + 3); r.time = 0.0f;
+    float d = 0.0f;
+    hit[i] = aabb_intersects(ld3(boxes + 6 * i), ld3(boxes + 6 * i + 3), r, maxd[i], d) ? 1 : 0;
+    dist[i] = d;
+}
+__global__ void probe_sphere_kernel(size_t n, const float* rays, const float* spheres, float* out_t) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = ld3(rays + 6 * i); r.d = ld3(rays + 6 * i + 3); r.time = 0.0f;
+    out_t[i] = sphere_closest_intersection(r, ld3(spheres + 4 * i), spheres[4 * i + 3]);
+}
+__global__ void probe_trace_kernel(DeviceWorld w, size_t n, const float* rays, int32_t* hit, float* t, int32_t* prim, float* normal) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = ld3(rays + 7 * i); r.d = ld3(rays + 7 * i + 3); r.time = rays[7 * i + 6];
+    HitRec rec;
+    rec.distance = RT_MISS_DIST; rec.normal = mk3(0.0f); rec.prim = -1; rec.mat = 0;
+    hit[i] = world_closest_intersection(w, r, rec) ? 1 : 0;
+    t[i] = rec.distance; prim[i] = rec.prim;
+    st3(normal + 3 * i, rec.normal);
+}
+__global__ void probe_scatter_kernel(uint64_t seed, size_t n, const rt_material* mats, const float* rays, const float* dist,
+                                     const float* normals, const uint32_t* keys, int32_t* scattered, float* out_rays,
+                                     float* atten, uint32_t* draws) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray in;
+    in.o = ld3(rays + 7 * i); in.d = ld3(rays + 7 * i + 3); in.time = rays[7 * i + 6];
+    HitRec rec;
+    rec.distance = dist[i]; rec.normal = ld3(normals + 3 * i); rec.prim = 0; rec.mat = 0;
+    Rng g;
+    g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
+    Ray out;
+    out.o = mk3(0.0f); out.d = mk3(0.0f); out.time = 0.0f;
+    f3 att = mk3(0.0f);
+    scattered[i] = material_scatter(mats[i], in, rec, g, out, att) ? 1 : 0;
+    st3(out_rays + 7 * i, out.o); st3(out_rays + 7 * i + 3, out.d); out_rays[7 * i + 6] = out.time;
+    st3(atten + 3 * i, att);
+    draws[i] = g.draw;
+}
+__global__ void probe_camera_kernel(uint64_t seed, rt_camera cam, size_t n, const float* st, const uint32_t* keys, float* out_rays, uint32_t* draws) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng g;
+    g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
+    Ray r = camera_sample_ray(cam, st[2 * i], st[2 * i + 1], g);
+    st3(out_rays + 7 * i, r.o); st3(out_rays + 7 * i + 3, r.d); out_rays[7 * i + 6] = r.time;
+    draws[i] = g.draw;
+}
+__global__ void probe_radiance_kernel(DeviceWorld w, rt_camera cam, uint32_t width, uint32_t height, uint32_t max_depth,
+                                      uint64_t seed, size_t n, const uint32_t* keys, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    f3 rad = one_sample(w, cam, width, height, max_depth, seed, keys[2 * i], keys[2 * i + 1]);
+    st3(out + 3 * i, rad);
+}
+// google_testing/test.cpp:112-135 (_sphere_index_ker)
+__global__ void probe_sphere_index_kernel(const float* spheres, int sphere_count, rt_camera cam, int width, int height, int32_t* results) {
+    int x_id = blockDim.x * blockIdx.x + threadIdx.x;
+    int y_id = blockDim.y * blockIdx.y + threadIdx.y;
+    if (x_id >= width || y_id >= height) return;
+    int gid = y_id * width + x_id;
+    float u = (float)x_id / ((float)width - 1.0f) * 2 - 1;
+    float v = (float)y_id / ((float)height - 1.0f) * 2 - 1;
+    Ray ray;
+    ray.o = mk3(cam.o[0], cam.o[1], cam.o[2]);
+    ray.d = mk3(cam.w[0], cam.w[1], cam.w[2]) + mk3(cam.u[0], cam.u[1], cam.u[2]) * u + mk3(cam.v[0], cam.v[1], cam.v[2]) * v;
+    ray.time = 0.0f;
+    float best = RT_MISS_DIST;
+    int result_index = -1;
+    for (int i = 0; i < sphere_count; i++) {
+        float dist = sphere_closest_intersection(ray, ld3(spheres + 4 * i), spheres[4 * i + 3]);
+        if (dist < best) { result_index = i; best = dist; }
+    }
+    results[gid] = result_index;
+}
+__global__ void probe_rng_kernel(uint64_t seed, size_t n, const uint32_t* keys, uint32_t n_draws, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng g;
+    g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
+    for (uint32_t k = 0; k < n_draws; k++) out[i * n_draws + k] = g.next();
+}
+
+#define PROBE_GRID(n) dim3((unsigned)(((n) + 127) / 128)), dim3(128)
+#define UP(buf, src, bytes) HIP_TRY((buf).upload((src), (bytes)))
+#define DOWN(dst, buf, bytes) HIP_TRY(hipMemcpy((dst), (buf).p, (bytes), hipMemcpyDeviceToHost))
+#define FINISH()                     \
+    HIP_TRY(hipGetLastError());      \
+    HIP_TRY(hipDeviceSynchronize())
+
+extern "C" int rt_probe_aabb(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out_hit, float* out_dist) {
+    if (!boxes || !rays || !max_dist || !out_hit || !out_dist) return rt_fail(RT_ERR_INVALID, "rt_probe_aabb: null argument");
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf b, r, m, h, d;
+    UP(b, boxes, n * 24); UP(r, rays, n * 24); UP(m, max_dist, n * 4);
+    HIP_TRY(h.alloc(n * 4)); HIP_TRY(d.alloc(n * 4));
+    probe_aabb_kernel<<<PROBE_GRID(n)>>>(n, b.as<float>(), r.as<float>(), m.as<float>(), h.as<int32_t>(), d.as<float>());
+    FINISH();
+    DOWN(out_hit, h, n * 4); DOWN(out_dist, d, n * 4);
+    return RT_OK;
+}
+extern "C" int rt_probe_sphere(int device, size_t n, const float* rays, const float* spheres, float* out_t) {
+    if (!rays || !spheres || !out_t) return rt_fail(RT_ERR_INVALID, "rt_probe_sphere: null argument");
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf r, s, t;
+    UP(r, rays, n * 24); UP(s, spheres, n * 16);
+    HIP_TRY(t.alloc(n * 4));
+    probe_sphere_kernel<<<PROBE_GRID(n)>>>(n, r.as<float>(), s.as<float>(), t.as<float>());
+    FINISH();
+    DOWN(out_t, t, n * 4);
+    return RT_OK;
+}
+extern "C" int rt_probe_trace(int device, const rt_world_flat* world, size_t n, const float* rays, int32_t* out_hit, float* out_t,
+                              int32_t* out_prim, float* out_normal) {
+    if (!rays || !out_hit || !out_t || !out_prim || !out_normal) return rt_fail(RT_ERR_INVALID, "rt_probe_trace: null argument");
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DeviceScene sc;
+    rc = sc.upload(world);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    DevBuf r, h, t, p, nn;
+    UP(r, rays, n * 28);
+    HIP_TRY(h.alloc(n * 4)); HIP_TRY(t.alloc(n * 4)); HIP_TRY(p.alloc(n * 4)); HIP_TRY(nn.alloc(n * 12));
+    probe_trace_kernel<<<PROBE_GRID(n)>>>(sc.dw, n, r.as<float>(), h.as<int32_t>(), t.as<float>(), p.as<int32_t>(), nn.as<float>());
+    FINISH();
+    DOWN(out_hit, h, n * 4); DOWN(out_t, t, n * 4); DOWN(out_prim, p, n * 4); DOWN(out_normal, nn, n * 12);
+    return RT_OK;
+}
+extern "C" int rt_probe_scatter(int device, uint64_t seed, size_t n, const rt_material* mats, const float* rays, const float* dist,
+                                const float* normals, const uint32_t* keys, int32_t* out_scattered, float* out_rays, float* out_atten,
+                                uint32_t* out_draws) {
+    if (!mats || !rays || !dist || !normals || !keys || !out_scattered || !out_rays || !out_atten || !out_draws)
+        return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: null argument");
+    if (n == 0) return RT_OK;
+    for (size_t i = 0; i < n; i++)
+        if (mats[i].type > RT_MAT_LAMBERTIAN_CHECKER) return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: case %zu: unknown material type", i);
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf m, r, d, nn, k, s, orr, a, dr;
+    UP(m, mats, n * sizeof(rt_material)); UP(r, rays, n * 28); UP(d, dist, n * 4); UP(nn, normals, n * 12); UP(k, keys, n * 8);
+    HIP_TRY(s.alloc(n * 4)); HIP_TRY(orr.alloc(n * 28)); HIP_TRY(a.alloc(n * 12)); HIP_TRY(dr.alloc(n * 4));
+    probe_scatter_kernel<<<PROBE_GRID(n)>>>(seed, n, m.as<rt_material>(), r.as<float>(), d.as<float>(), nn.as<float>(), k.as<uint32_t>(),
+                                            s.as<int32_t>(), orr.as<float>(), a.as<float>(), dr.as<uint32_t>());
+    FINISH();
+    DOWN(out_scattered, s, n * 4); DOWN(out_rays, orr, n * 28); DOWN(out_atten, a, n * 12); DOWN(out_draws, dr, n * 4);
+    return RT_OK;
+}
+extern "C" int rt_probe_camera(int device, uint64_t seed, const rt_camera* cam, size_t n, const float* st, const uint32_t* keys,
+                               float* out_rays, uint32_t* out_draws) {
+    if (!cam || !st || !keys || !out_rays || !out_draws) return rt_fail(RT_ERR_INVALID, "rt_probe_camera: null argument");
+    if (cam->type > RT_CAM_MOTION) return rt_fail(RT_ERR_INVALID, "rt_probe_camera: unknown camera type");
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf s, k, r, d;
+    UP(s, st, n * 8); UP(k, keys, n * 8);
+    HIP_TRY(r.alloc(n * 28)); HIP_TRY(d.alloc(n * 4));
+    probe_camera_kernel<<<PROBE_GRID(n)>>>(seed, *cam, n, s.as<float>(), k.as<uint32_t>(), r.as<float>(), d.as<uint32_t>());
+    FINISH();
+    DOWN(out_rays, r, n * 28); DOWN(out_draws, d, n * 4);
+    return RT_OK;
+}
+extern "C" int rt_probe_radiance(const rt_render_config* cfg, const rt_camera* cam, const rt_world_flat* world, size_t n,
+                                 const uint32_t* keys, float* out_radiance) {
+    if (!cfg || !cam || !keys || !out_radiance) return rt_fail(RT_ERR_INVALID, "rt_probe_radiance: null argument");
+    if (cfg->width == 0 || cfg->height == 0) return rt_fail(RT_ERR_INVALID, "rt_probe_radiance: empty image");
+    if (cam->type > RT_CAM_MOTION) return rt_fail(RT_ERR_INVALID, "rt_probe_radiance: unknown camera type");
+    for (size_t i = 0; i < n; i++)
+        if (keys[2 * i] >= cfg->width * cfg->height) return rt_fail(RT_ERR_INVALID, "rt_probe_radiance: key %zu: pixel out of range", i);
+    int rc = select_device(cfg->device);
+    if (rc != RT_OK) return rc;
+    DeviceScene sc;
+    rc = sc.upload(world);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    DevBuf k, o;
+    UP(k, keys, n * 8);
+    HIP_TRY(o.alloc(n * 12));
+    probe_radiance_kernel<<<PROBE_GRID(n)>>>(sc.dw, *cam, cfg->width, cfg->height, cfg->max_depth, cfg->seed, n, k.as<uint32_t>(), o.as<float>());
+    FINISH();
+    DOWN(out_radiance, o, n * 12);
+    return RT_OK;
+}
+extern "C" int rt_probe_sphere_index(int device, const rt_camera* cam, uint32_t width, uint32_t height, size_t n_spheres,
+                                     const float* spheres, int32_t* out_index) {
+    if (!cam || !spheres || !out_index) return rt_fail(RT_ERR_INVALID, "rt_probe_sphere_index: null argument");
+    if (width == 0 || height == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf s, o;
+    UP(s, spheres, n_spheres * 16);
+    HIP_TRY(o.alloc((size_t)width * height * 4));
+    dim3 threads(8, 8, 1);  // test.cpp:153-155
+    dim3 blocks((width + 7) / 8, (height + 7) / 8, 1);
+    probe_sphere_index_kernel<<<blocks, threads>>>(s.as<float>(), (int)n_spheres, *cam, (int)width, (int)height, o.as<int32_t>());
+    FINISH();
+    DOWN(out_index, o, (size_t)width * height * 4);
+    return RT_OK;
+}
+extern "C" int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t* keys, uint32_t n_draws, float* out) {
+    if (!keys || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_rng: null argument");
+    if (n == 0 || n_draws == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf k, o;
+    UP(k, keys, n * 8);
+    HIP_TRY(o.alloc(n * n_draws * 4));
+    probe_rng_kernel<<<PROBE_GRID(n)>>>(seed, n, k.as<uint32_t>(), n_draws, o.as<float>());
+    FINISH();
+    DOWN(out, o, n * n_draws * 4);
+    return RT_OK;
+}

@@ -1,0 +1,278 @@
+// rt_device_funcs.hpp — the hot-path functions as flat, non-virtual device code.
+//
+// The reference dispatches Hittable::ClosestIntersection and Material::Scatter through device
+// vtables (rt_engine/geometry/hittable.cuh:18, rt_engine/shaders/material.cuh:24-28) and chases
+// hittables[i] -> SphereHittable{vptr,sphere*,mat*} -> Sphere (3 dependent loads per leaf).  Here
+// the world is three linear arrays and every call is a switch on a tag.  Arithmetic follows the
+// reference expression by expression (rt_math.hpp) so the CPU oracle and the GPU agree bit for bit.
+#pragma once
+#include "rt06.h"
+#include "rt_internal.hpp"
+#include "rt_math.hpp"
+
+struct DeviceWorld {
+    uint32_t kind;
+    int32_t root;
+    uint32_t n_nodes, n_prims, n_mats;
+    f3 bmin, bmax;
+    const rt_bvh_node* nodes;
+    const rt_prim* prims;
+    const rt_material* mats;
+};
+
+// RayPayload (ray_data.cuh:33-40) with Sphere::TraceRecord (SphereHittable.cuh:38-41) unpacked
+struct HitRec {
+    float distance;
+    f3 normal;
+    int32_t prim;
+    uint32_t mat;
+};
+
+// aabb::intersects, rt_engine/geometry/aabb.cuh:30-44
+RT_HD bool aabb_intersects(f3 box_min, f3 box_max, const Ray& ray, float ray_max_dist, float& dist) {
+    f3 bmin = (box_min - ray.o) / ray.d;
+    f3 bmax = (box_max - ray.o) / ray.d;
+    f3 tmp_min = glm_min(bmin, bmax);
+    bmax = glm_max(bmin, bmax);
+    bmin = tmp_min;
+    float tmin = comp_max(bmin);
+    float tmax = comp_min(bmax);
+    bool hit = tmin <= tmax && tmin < ray_max_dist && tmax > 0;
+    if (hit) dist = tmin;
+    return hit;
+}
+
+// _sphere_closest_intersection, rt_engine/geometry/SphereHittable.cuh:15-33
+RT_HD float sphere_closest_intersection(const Ray& ray, f3 center, float radius) {
+    f3 oc = ray.o - center;
+    float a = dot(ray.d, ray.d);
+    float hb = dot(ray.d, oc);
+    float c = dot(oc, oc) - radius * radius;
+    float d = hb * hb - a * c;
+    if (d <= 0) return RT_MISS_DIST;
+    d = sqrtf(d);
+    float t = (-hb - d) / a;
+    if (t < 0.0f) {
+        t = (-hb + d) / a;
+        if (t < 0.0f) return RT_MISS_DIST;
+    }
+    return t;
+}
+
+// SphereHittable::ClosestIntersection (SphereHittable.cu:56-66) /
+// MovingSphereHittable::ClosestIntersection (:91-102)
+RT_HD bool prim_closest_intersection(const rt_prim& p, int32_t idx, const Ray& ray, HitRec& rec) {
+    f3 center = mk3(p.c0[0], p.c0[1], p.c0[2]);
+    if (p.mat & RT_PRIM_MOVING) center = mix(center, mk3(p.c1[0], p.c1[1], p.c1[2]), ray.time);
+    float t = sphere_closest_intersection(ray, center, p.radius);
+    if (t >= rec.distance) return false;
+    rec.mat = p.mat & ~RT_PRIM_MOVING;
+    rec.distance = t;
+    rec.prim = idx;
+    rec.normal = (ray_at(ray, rec.distance) - center) / p.radius;
+    return true;
+}
+
+RT_HD bool node_box(const rt_bvh_node& n, const Ray& ray, float maxd, float& dist) {
+    return aabb_intersects(mk3(n.min[0], n.min[1], n.min[2]), mk3(n.max[0], n.max[1], n.max[2]), ray, maxd, dist);
+}
+
+// BVH::ClosestIntersection, rt_engine/geometry/BVH.cu:54-106 (the live, non-priority-queue branch):
+// root box first; pop; leaf -> primitive; inner -> test BOTH child boxes, order near-first, push far
+// then near iff dist < rec.distance; no re-check at pop.
+__device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+    int32_t stack[RT_MAX_STACK];
+    int head = 0;
+    float root_dist;
+    if (!node_box(w.nodes[w.root], ray, rec.distance, root_dist)) return false;
+    stack[head++] = w.root;
+    bool hit_any = false;
+    while (head != 0) {
+        int32_t idx = stack[--head];
+        const rt_bvh_node& node = w.nodes[idx];
+        int32_t left_idx = node.left, right_idx = node.right;
+        if (left_idx == -1) {
+            hit_any |= prim_closest_intersection(w.prims[right_idx], right_idx, ray, rec);
+            continue;
+        }
+        float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+        node_box(w.nodes[left_idx], ray, rec.distance, left_dist);
+        node_box(w.nodes[right_idx], ray, rec.distance, right_dist);
+        if (left_dist > right_dist) {
+            int32_t ti = left_idx; left_idx = right_idx; right_idx = ti;
+            float tf = left_dist; left_dist = right_dist; right_dist = tf;
+        }
+        if (right_dist < rec.distance) stack[head++] = right_idx;
+        if (left_dist < rec.distance) stack[head++] = left_idx;
+    }
+    return hit_any;
+}
+
+// HittableList::ClosestIntersection, rt_engine/geometry/HittableList.cuh:21-34
+__device__ inline bool list_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+    float d;
+    if (!aabb_intersects(w.bmin, w.bmax, ray, rec.distance, d)) return false;
+    bool hit_any = false;
+    for (uint32_t i = 0; i < w.n_prims; i++)
+        if (prim_closest_intersection(w.prims[i], (int32_t)i, ray, rec)) hit_any = true;
+    return hit_any;
+}
+
+// bvh_node::ClosestIntersection, rt_engine/geometry/bvh_node.cuh:19-24, made iterative: the recursion
+// "own box, then left subtree, then right subtree" is a pre-order walk, i.e. pop / test / push right /
+// push left with the box test at visit time against the current rec.distance.
+__device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+    int32_t stack[RT_MAX_STACK];
+    int head = 0;
+    stack[head++] = w.root;
+    bool hit_any = false;
+    while (head != 0) {
+        int32_t ref = stack[--head];
+        if (ref < 0) {
+            int32_t pi = -ref - 1;
+            hit_any |= prim_closest_intersection(w.prims[pi], pi, ray, rec);
+            continue;
+        }
+        const rt_bvh_node& n = w.nodes[ref];
+        float d;
+        if (!node_box(n, ray, rec.distance, d)) continue;
+        stack[head++] = n.right;
+        stack[head++] = n.left;
+    }
+    return hit_any;
+}
+
+__device__ inline bool world_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+    if (w.kind == RT_WORLD_BVH) return bvh_closest_intersection(w, ray, rec);
+    if (w.kind == RT_WORLD_LIST) return list_closest_intersection(w, ray, rec);
+    return tree_closest_intersection(w, ray, rec);
+}
+
+// reflectance, rt_engine/shaders/cu_materials.cuh:99-104.  powf(1-cos,5) is evaluated as
+// x2=x*x; x4=x2*x2; x5=x4*x on BOTH sides of the parity check: libm, OCML and CUDA powf differ in
+// the last ulp, and that ulp decides `reflect_prob > rng.next()`.
+RT_HD float reflectance(float cos_theta, float ior_ratio) {
+    float r0 = (1 - ior_ratio) / (1 + ior_ratio);
+    r0 = r0 * r0;
+    float x = 1 - cos_theta;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    float x5 = x4 * x;
+    return r0 + (1 - r0) * x5;
+}
+
+// checker_texture::value, rt_engine/shaders/cu_Textures.cuh:31-39 (ivec3 truncates toward zero)
+RT_HD f3 checker_value(const rt_material& m, f3 pos) {
+    f3 sp = pos * m.param;
+    int ix = (int)sp.x, iy = (int)sp.y, iz = (int)sp.z;
+    int sum = 0;
+    sum += ix; sum += iy; sum += iz;
+    return (sum % 2 == 0) ? mk3(m.albedo[0], m.albedo[1], m.albedo[2]) : mk3(m.albedo2[0], m.albedo2[1], m.albedo2[2]);
+}
+
+// Material::Scatter — LambertianAbstract (cu_materials.cuh:52-64), MetalAbstract (:77-95),
+// DielectricAbstract (:115-143), LambertianTexture (:27-40)
+RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRec& rec, Rng& rng, Ray& out, f3& attenuation) {
+    f3 normal = rec.normal;
+    if (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LAMBERTIAN_CHECKER) {
+        f3 ray_dir = normal + rng_on_unit3(rng);
+        if (near_zero(ray_dir)) return false;
+        out.o = ray_at(in_ray, rec.distance); out.d = ray_dir; out.time = in_ray.time;
+        attenuation = (m.type == RT_MAT_LAMBERTIAN) ? mk3(m.albedo[0], m.albedo[1], m.albedo[2])
+                                                    : checker_value(m, ray_at(in_ray, rec.distance));
+        return true;
+    }
+    if (m.type == RT_MAT_METAL) {
+        f3 scatter_dir = reflect(in_ray.d, normal) + rng_on_unit3(rng) * m.param;
+        if (dot(scatter_dir, normal) < 0 || near_zero(scatter_dir)) return false;
+        out.o = ray_at(in_ray, rec.distance); out.d = scatter_dir; out.time = in_ray.time;
+        attenuation = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+        return true;
+    }
+    float ior = m.param;
+    bool hit_backface = dot(in_ray.d, normal) > 0;  // isBackfacing, ray_data.cuh:44-46
+    if (hit_backface) normal = -normal;
+    float ior_ratio = hit_backface ? ior : 1 / ior;
+    f3 unit_dir = normalize(in_ray.d);
+    float cos_theta = fminf(dot(-unit_dir, normal), 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float reflect_prob = reflectance(cos_theta, ior_ratio);
+    f3 scatter_dir;
+    if (ior_ratio * sin_theta > 1.0f || reflect_prob > rng.next()) scatter_dir = reflect(unit_dir, normal);
+    else scatter_dir = refract(unit_dir, normal, ior_ratio);
+    out.o = ray_at(in_ray, rec.distance); out.d = scatter_dir; out.time = in_ray.time;
+    attenuation = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    return true;
+}
+
+// sample_ray — PinholeCamera (cu_Cameras.cuh:27-30), DefocusBlurCamera (:54-64), MotionBlurCamera (:87-89)
+RT_HD Ray camera_sample_ray(const rt_camera& c, float s, float t, Rng& rng) {
+    Ray r;
+    f3 o = mk3(c.o[0], c.o[1], c.o[2]), u = mk3(c.u[0], c.u[1], c.u[2]);
+    f3 v = mk3(c.v[0], c.v[1], c.v[2]), w = mk3(c.w[0], c.w[1], c.w[2]);
+    if (c.type == RT_CAM_DEFOCUS) {
+        float dx, dy;
+        rng_in_unit2(rng, dx, dy);
+        f3 offset = u * dx + v * dy;
+        offset = offset * c.lens_radius;
+        f3 forward = w * c.focus_dist;
+        f3 hori = u * c.viewport_width * c.focus_dist;
+        f3 vert = v * c.viewport_height * c.focus_dist;
+        r.o = o + offset;
+        r.d = forward + hori * s + vert * t - offset;
+        r.time = 0.0f;
+    } else {
+        r.o = o;
+        r.d = w + u * s + v * t;
+        r.time = (c.type == RT_CAM_MOTION) ? mix(c.t0, c.t1, rng.next()) : 0.0f;
+    }
+    return r;
+}
+
+// sample_world, main/src/Renderer.cu:139-181
+__device__ inline f3 sample_world(const DeviceWorld& w, Ray cur_ray, uint32_t max_depth, Rng& rng) {
+    f3 accum_attenuation = mk3(1.0f);
+    for (uint32_t i = 0; i < max_depth; i++) {
+        HitRec rec;
+        rec.distance = RT_MISS_DIST; rec.normal = mk3(0.0f); rec.prim = -1; rec.mat = 0;
+        if (!world_closest_intersection(w, cur_ray, rec)) {
+            float t = normalize(cur_ray.d).y * 0.5f + 0.5f;
+            f3 sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
+            return accum_attenuation * sky;
+        }
+        Ray scattered;
+        f3 attenuation;
+        if (!material_scatter(w.mats[rec.mat], cur_ray, rec, rng, scattered, attenuation)) return mk3(0.0f);
+        accum_attenuation = accum_attenuation * attenuation;
+        cur_ray = scattered;
+        cur_ray.o = cur_ray.o + cur_ray.d * 0.001f;
+    }
+    return mk3(0.0f);
+}
+
+// pixel centre in NDC, Renderer.cu:188-192
+RT_HD void pixel_ndc(uint32_t x, uint32_t y, uint32_t width, uint32_t height, float& psx, float& psy, float& ndcx, float& ndcy) {
+    psx = 1.0f / (float)width;
+    psy = 1.0f / (float)height;
+    ndcx = ((float)x + 0.5f) * psx * 2.0f - 1.0f;
+    ndcy = ((float)y + 0.5f) * psy * 2.0f - 1.0f;
+}
+
+// camera ray of one sample: jitter in a disc of half a pixel, then sample_ray (Renderer.cu:199-201).
+// The RNG is keyed per (pixel, sample) — SURVEY.md Appendix A item 7.
+RT_HD Ray primary_ray(const rt_camera& cam, uint32_t width, uint32_t height, uint32_t gid, Rng& rng) {
+    uint32_t x = gid % width, y = gid / width;
+    float psx, psy, ndcx, ndcy;
+    pixel_ndc(x, y, width, height, psx, psy, ndcx, ndcy);
+    float jx, jy;
+    rng_in_unit2(rng, jx, jy);
+    return camera_sample_ray(cam, ndcx + jx * psx, ndcy + jy * psy, rng);
+}
+
+__device__ inline f3 one_sample(const DeviceWorld& w, const rt_camera& cam, uint32_t width, uint32_t height,
+                                uint32_t max_depth, uint64_t seed, uint32_t gid, uint32_t s) {
+    Rng rng;
+    rng.init(seed, gid, s, RT_STREAM_RENDER);
+    Ray ray = primary_ray(cam, width, height, gid, rng);
+    return sample_world(w, ray, max_depth, rng);
+}

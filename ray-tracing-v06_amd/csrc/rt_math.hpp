@@ -1,0 +1,146 @@
+// rt_math.hpp — fp32 vector vocabulary shared by the host scene code and the HIP kernels.
+//
+// The reference does all its math through GLM (glm::vec3, vendored 0.9.9.7); the hot path needs a
+// dozen functions of it.  They are re-implemented here as a tiny POD `f3` with GLM's exact
+// evaluation order and NaN semantics, because CPU/GPU parity on this path is a bit-exactness
+// problem (one flipped hit/miss or rejection-loop branch moves a pixel by 1/spp).  Everything is
+// compiled with -ffp-contract=off (no FMA contraction) and correctly rounded / and sqrtf.
+// Citations: glm/ = /root/reference/Libraries/include/glm, utils = main/src/utilities/glm_utils.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define RT_HD __host__ __device__ __forceinline__
+
+#define RT_MISS_DIST 3.402823466e+38F  // _MISS_DIST, rt_engine/ray_data.cuh:17
+
+struct f3 {
+    float x, y, z;
+};
+
+RT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD f3 mk3(float s) { return mk3(s, s, s); }
+RT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+RT_HD void st3(float* p, f3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+RT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD f3 operator/(f3 a, f3 b) { return mk3(a.x / b.x, a.y / b.y, a.z / b.z); }
+RT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RT_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+
+// glm/detail/func_common.inl:17-30 — NOT fminf/fmaxf: a NaN in x is returned, a NaN in y is dropped.
+RT_HD float glm_min(float x, float y) { return (y < x) ? y : x; }
+RT_HD float glm_max(float x, float y) { return (x < y) ? y : x; }
+RT_HD f3 glm_min(f3 a, f3 b) { return mk3(glm_min(a.x, b.x), glm_min(a.y, b.y), glm_min(a.z, b.z)); }
+RT_HD f3 glm_max(f3 a, f3 b) { return mk3(glm_max(a.x, b.x), glm_max(a.y, b.y), glm_max(a.z, b.z)); }
+// glm/gtx/component_wise.inl:111-126
+RT_HD float comp_min(f3 a) { float r = a.x; r = glm_min(r, a.y); r = glm_min(r, a.z); return r; }
+RT_HD float comp_max(f3 a) { float r = a.x; r = glm_max(r, a.y); r = glm_max(r, a.z); return r; }
+// glm/detail/func_geometric.inl:48-56
+RT_HD float dot(f3 a, f3 b) { f3 t = a * b; return t.x + t.y + t.z; }
+// glm/detail/func_geometric.inl:70-81
+RT_HD f3 cross(f3 x, f3 y) { return mk3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+// glm/detail/func_geometric.inl:84-93, func_exponential.inl:134-139
+RT_HD f3 normalize(f3 a) { float inv = 1.0f / sqrtf(dot(a, a)); return a * inv; }
+// glm/detail/func_geometric.inl:104-110
+RT_HD f3 reflect(f3 i, f3 n) { return i - n * dot(n, i) * 2.0f; }
+// glm/detail/func_geometric.inl:113-123
+RT_HD f3 refract(f3 i, f3 n, float eta) {
+    float dv = dot(n, i);
+    float k = 1.0f - eta * eta * (1.0f - dv * dv);
+    if (k >= 0.0f) return i * eta - n * (eta * dv + sqrtf(k));
+    return mk3(0.0f);
+}
+// glm/detail/func_common.inl:104-112,124-132
+RT_HD f3 mix(f3 x, f3 y, float a) { return x * (1.0f - a) + y * a; }
+RT_HD float mix(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+// utils:15-25 (epsilon 1e-9f)
+RT_HD bool near_zero(f3 a) { return !(fabsf(a.x) > 1e-9f) && !(fabsf(a.y) > 1e-9f) && !(fabsf(a.z) > 1e-9f); }
+// utils:27-35
+RT_HD float length2(f3 a) { float s = 0.0f; s += a.x * a.x; s += a.y * a.y; s += a.z * a.z; return s; }
+RT_HD float length2(float x, float y) { float s = 0.0f; s += x * x; s += y * y; return s; }
+// utils:64-67
+RT_HD f3 linear_interpolate(f3 a, f3 b, float f) { return a + (b - a) * f; }
+// glm/detail/func_trigonometric.inl:9-14
+RT_HD float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+// Renderer.cu:209-211: glm::clamp(x,0,1) = min(max(x,0),1), then glm::sqrt
+RT_HD f3 clamp01_sqrt(f3 a) {
+    f3 c = glm_min(glm_max(a, mk3(0.0f)), mk3(1.0f));
+    return mk3(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
+}
+
+// Ray, rt_engine/ray_data.cuh:8-15
+struct Ray {
+    f3 o, d;
+    float time;
+};
+RT_HD f3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based RNG (Philox4x32-10) replacing cuRandom's per-pixel XORWOW state
+// (utilities/cuda_utilities/cuRandom.cuh:10-41; 48 B/pixel of global-memory state, Renderer.cu:191).
+// counter = (draw/4, sample, pixel, stream), key = seed lo/hi; no state in memory.
+// next() keeps curand_uniform's (0,1] range: u = ((word >> 8) + 1) * 2^-24, exact in fp32.
+// ---------------------------------------------------------------------------------------------
+#define RT_STREAM_RENDER 0u
+#define RT_STREAM_SCENE 0x5CE9E5u
+
+RT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+#else
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+#endif
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct Rng {
+    uint32_t k0, k1, sample, pixel, stream, draw;
+    uint32_t b0, b1, b2, b3;
+    RT_HD void init(uint64_t seed, uint32_t pixel_, uint32_t sample_, uint32_t stream_) {
+        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
+        pixel = pixel_; sample = sample_; stream = stream_; draw = 0;
+        b0 = b1 = b2 = b3 = 0;
+    }
+    // cuRandom::next(), cuRandom.cuh:21
+    RT_HD float next() {
+        uint32_t lane = draw & 3u;
+        if (lane == 0u) {
+            uint32_t o[4];
+            philox4x32_10(draw >> 2, sample, pixel, stream, k0, k1, o);
+            b0 = o[0]; b1 = o[1]; b2 = o[2]; b3 = o[3];
+        }
+        uint32_t w = lane == 0u ? b0 : (lane == 1u ? b1 : (lane == 2u ? b2 : b3));
+        draw++;
+        return (float)((w >> 8) + 1u) * 5.9604644775390625e-08f;
+    }
+};
+// glm::cuRandomInUnit<2>, utils:84-90
+RT_HD void rng_in_unit2(Rng& g, float& ox, float& oy) {
+    for (;;) {
+        float x = g.next() * 2.0f - 1.0f;
+        float y = g.next() * 2.0f - 1.0f;
+        if (length2(x, y) < 1.0f) { ox = x; oy = y; return; }
+    }
+}
+// glm::cuRandomOnUnit<3>, utils:92-98
+RT_HD f3 rng_on_unit3(Rng& g) {
+    for (;;) {
+        f3 v;
+        v.x = g.next() * 2.0f - 1.0f;
+        v.y = g.next() * 2.0f - 1.0f;
+        v.z = g.next() * 2.0f - 1.0f;
+        if (!near_zero(v) && length2(v) < 1.0f) return normalize(v);
+    }
+}

@@ -95,6 +95,9 @@ def lib():
     L.orc_render.argtypes = [C.POINTER(World), C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                              C.c_uint64, C.c_int, f32p, C.POINTER(Counters)]
     L.orc_render.restype = C.c_int
+    L.orc_render_pixels.argtypes = [C.POINTER(World), C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint64, C.c_size_t, u32p, f32p]
+    L.orc_render_pixels.restype = C.c_int
     for name in ("orc_scene_book1_final", "orc_scene_book2_moving"):
         getattr(L, name).argtypes = [C.c_uint64]
         getattr(L, name).restype = C.c_void_p
@@ -189,3 +192,12 @@ def render(world, cam, width, height, spp, max_depth, seed=1984, threads=None):
     if rc != 0:
         raise RuntimeError(f"orc_render failed rc={rc}")
     return out, cnt
+
+
+def render_pixels(world, cam, width, height, spp, max_depth, gids, seed=1984):
+    gids = np.ascontiguousarray(gids, dtype=np.uint32)
+    out = np.zeros((len(gids), 4), dtype=np.float32)
+    rc = lib().orc_render_pixels(C.byref(world), C.byref(cam), width, height, spp, max_depth, seed, len(gids), gids, out)
+    if rc != 0:
+        raise RuntimeError(f"orc_render_pixels failed rc={rc}")
+    return out

@@ -1,0 +1,166 @@
+"""CPU tests (-m "not gpu"): the product's HOST side against the oracle, and the C-ABI surface.
+
+No kernel is launched here: scene generation, BVH builders, flattening and camera construction run on
+the host inside librt06.so and must agree bit-for-bit with the oracle's independent C restatement.
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from _common import ROOT, as_oracle_world, bits_equal, config_cameras, oracle_scene, pkg
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    p = pkg()
+    L = p.lib()
+    header = open(os.path.join(ROOT, "include", "rt06.h")).read()
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rt_bvh_node", "rt_prim", "rt_material", "rt_world_flat", "rt_camera"}
+    assert declared == set(p.capi.SYMBOLS), declared ^ set(p.capi.SYMBOLS)
+    for name in declared:
+        assert hasattr(L, name), f"librt06.so does not export {name}"
+    assert b"gfx950" in L.rt_version()
+
+
+def test_struct_layouts_match_header_sizes():
+    p = pkg()
+    assert p.capi.NODE_DT.itemsize == 32 and p.capi.PRIM_DT.itemsize == 32 and p.capi.MAT_DT.itemsize == 32
+    assert C.sizeof(p.capi.Camera) == 76
+    assert C.sizeof(p.capi.WorldFlat) == C.sizeof(O.World) == 72
+    assert C.sizeof(p.capi.Camera) == C.sizeof(O.Camera)
+
+
+@pytest.mark.parametrize("which", ["book1_final", "book2_moving", "three_spheres"])
+def test_prefab_scene_matches_oracle_bit_for_bit(which):
+    p = pkg()
+    s = getattr(p.Scene, which)() if which == "three_spheres" else getattr(p.Scene, which)(1984)
+    o = oracle_scene(which)
+    w, ow = s.getWorldPtr(), o.world
+    for f in ("kind", "root", "n_nodes", "n_prims", "n_materials", "max_stack"):
+        assert getattr(w, f) == getattr(ow, f), f
+    assert bits_equal(np.array(w.bounds_min[:]), np.array(ow.bounds_min[:]))
+    assert bits_equal(np.array(w.bounds_max[:]), np.array(ow.bounds_max[:]))
+    nodes, prims, mats = s.arrays()
+    assert nodes.tobytes() == o.nodes.tobytes()
+    assert prims.tobytes() == o.prims.tobytes()
+    assert mats.tobytes() == o.materials.tobytes()
+    if which != "three_spheres":
+        assert w.n_prims == 488 and w.n_nodes == 975 and w.root == 974
+
+
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_bvh_builders_match_oracle(builder, seed):
+    """_build_bvh_rec1 / _build_bvh_rec2 / BuildBVH_BottomUp / HittableList on random sphere sets."""
+    p = pkg()
+    rng = np.random.default_rng(seed)
+    n = 97 if builder != 2 else 41
+    s = p.Scene()
+    prims = np.zeros(n, dtype=O.PRIM_DT)
+    mats = np.zeros(n, dtype=O.MAT_DT)
+    for i in range(n):
+        c0 = (rng.random(3, dtype=np.float32) * 20 - 10).astype(np.float32)
+        moving = bool(i % 3 == 0)
+        c1 = (c0 + rng.random(3, dtype=np.float32)).astype(np.float32) if moving else c0
+        rad = np.float32(0.1 + rng.random() * 0.9)
+        albedo = rng.random(3, dtype=np.float32)
+        m = s.add_material(i % 3, albedo, float(np.float32(0.25)))
+        (s.MakeMovingSphere(c0, c1, rad, m) if moving else s.MakeSphere(c0, rad, m))
+        prims[i] = (c0, rad, c1, m | (0x80000000 if moving else 0))
+        mats[i] = (albedo, np.float32(0.25), (0, 0, 0), i % 3)
+    [s.BuildBVH_TopDown, s.BuildBVH_SAH, s.BuildBVH_BottomUp, s.MakeHittableList][builder]()
+    o = O.Scene.from_arrays(prims, mats, builder)
+    nodes, pprims, pmats = s.arrays()
+    w, ow = s.getWorldPtr(), o.world
+    assert (w.kind, w.root, w.n_nodes, w.max_stack) == (ow.kind, ow.root, ow.n_nodes, ow.max_stack)
+    assert nodes.tobytes() == o.nodes.tobytes()
+    assert pprims.tobytes() == o.prims.tobytes()
+    assert pmats.tobytes() == o.materials.tobytes()
+    assert bits_equal(np.array(w.bounds_min[:]), np.array(ow.bounds_min[:]))
+
+
+def test_bvh_structure_invariants():
+    p = pkg()
+    s = p.Scene.book1_final(7)
+    nodes, prims, _ = s.arrays()
+    w = s.getWorldPtr()
+    seen = np.zeros(len(prims), dtype=int)
+
+    def walk(i, depth):
+        n = nodes[i]
+        if n["left"] == -1:
+            seen[n["right"]] += 1
+            c, r = prims[n["right"]]["c0"], prims[n["right"]]["radius"]
+            assert np.all(n["min"] <= c - r) and np.all(n["max"] >= c + r)
+            return depth
+        for ch in (n["left"], n["right"]):
+            assert ch < i  # post-order numbering: children precede parents, root is last (BVH.cu:180-210)
+            assert np.all(nodes[ch]["min"] >= n["min"]) and np.all(nodes[ch]["max"] <= n["max"])
+        return max(walk(n["left"], depth + 1), walk(n["right"], depth + 1))
+
+    depth = walk(w.root, 0)
+    assert np.all(seen == 1)
+    assert w.max_stack == depth + 1 <= 32
+
+
+@pytest.mark.parametrize("which,W,H", [("three_spheres", 400, 225), ("book1_final", 1200, 800), ("book2_moving", 800, 800)])
+def test_cameras_match_oracle(which, W, H):
+    p = pkg()
+    cam = config_cameras(p, which, W, H)
+    if which == "three_spheres":
+        oc = O.camera_pinhole((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, W / H)
+    elif which == "book1_final":
+        oc = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    else:
+        oc = O.camera_motion((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.0, 1.0)
+    assert bytes(cam) == bytes(oc)
+
+
+def test_error_convention_is_never_silent():
+    p = pkg()
+    s = p.Scene()
+    with pytest.raises(p.capi.RtError, match="no world built"):
+        s.getWorldPtr()
+    with pytest.raises(p.capi.RtError, match="material index"):
+        s.MakeSphere((0, 0, 0), 1.0, 5)
+    with pytest.raises(p.capi.RtError, match="no primitives"):
+        s.BuildBVH_TopDown()
+    m = s.Lambertian((0.5, 0.5, 0.5))
+    s.MakeSphere((0, 0, 0), 1.0, m)
+    with pytest.raises(p.capi.RtError, match="bad child"):
+        s.bvh_node(5, -1)
+    with pytest.raises(p.capi.RtError, match="unknown material"):
+        s.add_material(9, (1, 1, 1))
+
+
+def test_bvh_stack_limit_is_checked():
+    """The reference's 32-entry traversal stack is never checked (BVH.cu:17,27-35); a degenerate chain
+    that would overflow it must be refused at build time."""
+    p = pkg()
+    s = p.Scene()
+    m = s.Lambertian((0.5, 0.5, 0.5))
+    prims = [s.MakeSphere((float(i), 0, 0), 0.4, m) for i in range(40)]
+    ref = s.prim_ref(prims[0])
+    for i in range(1, 40):
+        ref = s.bvh_node(ref, s.prim_ref(prims[i]))
+    with pytest.raises(p.capi.RtError, match="traversal stack"):
+        s.set_world_node_tree(ref)
+
+
+def test_oracle_renders_config1_three_spheres():
+    """BASELINE.json configs[0]: three-spheres 400x225, 1 spp, CPU reference path (plumbing, no GPU)."""
+    o = oracle_scene("three_spheres")
+    cam = O.camera_pinhole((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, 400 / 225)
+    img, cnt = O.render(o.world, cam, 400, 225, 1, 50)
+    assert cnt.samples == 400 * 225
+    assert np.all(img[..., 3] == 1.0)
+    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0
+    # sky at the top rows (row 0 = bottom), ground (yellow-green Lambertian) at the bottom
+    assert img[-1, :, 2].mean() > 0.6 and img[0, :, 2].mean() < 0.3
+    # thread-count independence of the oracle itself
+    img1, _ = O.render(o.world, cam, 400, 225, 1, 50, threads=1)
+    assert img1.tobytes() == img.tobytes()
