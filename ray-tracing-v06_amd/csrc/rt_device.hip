@@ -2,7 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "rt06.h"
@@ -10,6 +13,7 @@
 #include "rt_internal.hpp"
 #include "rt_math.hpp"
 #include "rt_render_kernels.hpp"
+#include "rt_stream_kernel.hpp"
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -22,6 +26,11 @@
 // small RAII helpers (host side)
 // ---------------------------------------------------------------------------------------------
 namespace {
+inline float __uint_as_float_host(uint32_t u) {
+    float f;
+    std::memcpy(&f, &u, sizeof(f));
+    return f;
+}
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
@@ -42,8 +51,61 @@ struct DevBuf {
 };
 
 struct DeviceScene {
-    DevBuf nodes, prims, mats;
+    DevBuf nodes, prims, mats, blob;
     DeviceWorld dw{};
+    PackedSceneRef packed{};  // valid when has_packed
+    bool has_packed = false;
+    uint32_t true_stack = 0;  // traversal-stack bound computed from the tree itself
+
+    // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 64-B wide nodes (both
+    // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
+    int pack(const rt_world_flat* w) {
+        has_packed = false;
+        if (w->kind != RT_WORLD_BVH) return RT_OK;
+        std::vector<int32_t> wide_of(w->n_nodes, -1);
+        uint32_t n_inner = 0;
+        for (uint32_t i = 0; i < w->n_nodes; i++)
+            if (w->nodes[i].left != -1) wide_of[i] = (int32_t)n_inner++;
+        auto ref_of = [&](int32_t node) -> int32_t {
+            const rt_bvh_node& n = w->nodes[node];
+            if (n.left != -1) return wide_of[node];
+            uint32_t prim = (uint32_t)n.right;
+            uint32_t code = prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u);
+            return -(int32_t)code - 1;
+        };
+        if (w->n_prims >= (1u << 29)) return RT_OK;  // leaf code would not fit
+        size_t n_vec4 = (size_t)n_inner * 4 + (size_t)w->n_prims * 2;
+        std::vector<uint4> host(n_vec4);
+        WideNode* wn = reinterpret_cast<WideNode*>(host.data());
+        for (uint32_t i = 0; i < w->n_nodes; i++) {
+            if (wide_of[i] < 0) continue;
+            const rt_bvh_node& n = w->nodes[i];
+            const rt_bvh_node& l = w->nodes[n.left];
+            const rt_bvh_node& r = w->nodes[n.right];
+            WideNode& o = wn[wide_of[i]];
+            for (int k = 0; k < 3; k++) { o.lmin[k] = l.min[k]; o.lmax[k] = l.max[k]; o.rmin[k] = r.min[k]; o.rmax[k] = r.max[k]; }
+            o.lref = ref_of(n.left); o.rref = ref_of(n.right);
+            o.pad[0] = o.pad[1] = 0;
+        }
+        float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)n_inner * 4);
+        float4* ext = sph + w->n_prims;
+        for (uint32_t i = 0; i < w->n_prims; i++) {
+            const rt_prim& pr = w->prims[i];
+            sph[i] = make_float4(pr.c0[0], pr.c0[1], pr.c0[2], pr.radius);
+            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(pr.mat & ~RT_PRIM_MOVING));
+        }
+        HIP_TRY(blob.upload(host.data(), n_vec4 * sizeof(uint4)));
+        packed.blob = blob.as<uint4>();
+        packed.blob_vec4 = (uint32_t)n_vec4;
+        packed.off_spheres = n_inner * 4;
+        packed.off_extra = n_inner * 4 + w->n_prims;
+        packed.root_ref = ref_of(w->root);
+        for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
+        packed.stack_cap = true_stack ? true_stack : 1u;
+        packed.mats = mats.as<rt_material>();
+        has_packed = true;
+        return RT_OK;
+    }
     int upload(const rt_world_flat* w) {
         if (!w) return rt_fail(RT_ERR_INVALID, "null world");
         if (w->kind > RT_WORLD_NODE_TREE) return rt_fail(RT_ERR_INVALID, "unknown world kind %u", w->kind);
@@ -72,6 +134,30 @@ struct DeviceScene {
                 if (!ok(w->nodes[i].left) || !ok(w->nodes[i].right) || w->nodes[i].left == (int32_t)i || w->nodes[i].right == (int32_t)i)
                     return rt_fail(RT_ERR_INVALID, "bvh_node %u: child reference out of range", i);
         }
+        // the node graph must be a tree no deeper than the traversal stack: a cycle would spin the GPU
+        // forever and a deeper tree would overrun the per-lane stack (the reference checks neither).
+        true_stack = 0;
+        if (w->kind != RT_WORLD_LIST) {
+            std::vector<uint8_t> seen(w->n_nodes, 0);
+            std::vector<std::pair<int32_t, uint32_t>> todo;  // (node, depth)
+            auto is_node = [&](int32_t r) { return w->kind == RT_WORLD_BVH ? true : r >= 0; };
+            uint32_t max_leaf_depth = 0;
+            if (is_node(w->root)) todo.push_back({w->root, 0u});
+            while (!todo.empty()) {
+                auto [ni, d] = todo.back();
+                todo.pop_back();
+                if (seen[ni]) return rt_fail(RT_ERR_INVALID, "node %d is reachable twice: the node graph is not a tree", ni);
+                seen[ni] = 1;
+                const rt_bvh_node& n = w->nodes[ni];
+                if (w->kind == RT_WORLD_BVH && n.left == -1) { max_leaf_depth = std::max(max_leaf_depth, d); continue; }
+                max_leaf_depth = std::max(max_leaf_depth, d + 1);
+                if (is_node(n.left)) todo.push_back({n.left, d + 1});
+                if (is_node(n.right)) todo.push_back({n.right, d + 1});
+            }
+            true_stack = max_leaf_depth + 1;
+            if (true_stack > RT_MAX_STACK)
+                return rt_fail(RT_ERR_STACK, "world needs a %u-entry traversal stack; limit %d (BVH.cu:17)", true_stack, RT_MAX_STACK);
+        }
         HIP_TRY(nodes.upload(w->nodes, sizeof(rt_bvh_node) * (size_t)w->n_nodes));
         HIP_TRY(prims.upload(w->prims, sizeof(rt_prim) * (size_t)w->n_prims));
         HIP_TRY(mats.upload(w->materials, sizeof(rt_material) * (size_t)w->n_materials));
@@ -80,7 +166,7 @@ struct DeviceScene {
         dw.bmin = mk3(w->bounds_min[0], w->bounds_min[1], w->bounds_min[2]);
         dw.bmax = mk3(w->bounds_max[0], w->bounds_max[1], w->bounds_max[2]);
         dw.nodes = nodes.as<rt_bvh_node>(); dw.prims = prims.as<rt_prim>(); dw.mats = mats.as<rt_material>();
-        return RT_OK;
+        return pack(w);
     }
 };
 
@@ -112,10 +198,95 @@ struct rt_renderer {
     TileMap tm{};
     DevBuf fb;
     DevBuf work_counter;
+    DevBuf samples, running;     // sample buffer of one pass; running sums when spp needs several passes
+    uint32_t pass_spp = 0;       // samples per pixel per pass
+    uint32_t n_cus = 0;
+    uint32_t stream_lds_bytes = 0;
+    uint32_t stream_blocks_per_cu = 0;
+    uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
     size_t shard_floats = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+
+    // Pick the kernel variant and size the per-pass sample buffer.
+    //   0 = default (the fastest validated variant), 1 = baseline wave-per-pixel kernel,
+    //   2 = streaming kernel with verbatim box tests, 3 = streaming kernel with the fast exact division.
+    int plan() {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, cfg.device));
+        n_cus = (uint32_t)prop.multiProcessorCount;
+        const uint32_t lds_per_cu = 160u * 1024u;  // MI355X_MICROARCH.md: 160 KiB LDS per CU
+        uint32_t want = cfg.variant;
+        if (want > 3) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
+        bool can_stream = scene.has_packed;
+        if (can_stream) {
+            stream_lds_bytes = scene.packed.blob_vec4 * 16u + (RT_STREAM_BLOCK / 64u) * 64u * scene.packed.stack_cap * 4u;
+            if (stream_lds_bytes > lds_per_cu) can_stream = false;
+            else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
+        }
+        if (want == 0) want = can_stream ? RT_DEFAULT_STREAM_VARIANT : 1u;
+        if (want >= 2 && !can_stream)
+            return rt_fail(RT_ERR_INVALID, "kernel variant %u needs an RT_WORLD_BVH world whose LDS image fits in 160 KiB", want);
+        variant = want;
+        if (variant >= 2) {
+            uint64_t budget = 8ull << 30;  // HBM for one pass of per-sample radiance (12 B each)
+            if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // tests force multi-pass rendering with this
+                unsigned long long v = std::strtoull(env, nullptr, 10);
+                if (v >= 12) budget = v;
+            }
+            uint64_t n_local_pixels = (uint64_t)tm.n_local_tiles * RT_TILE * RT_TILE;
+            uint64_t max_spp = std::max<uint64_t>(1, budget / (n_local_pixels * 12ull));
+            pass_spp = (uint32_t)std::min<uint64_t>(cfg.samples_per_pixel, max_spp);
+            if (n_local_pixels * pass_spp >= 0xF0000000ull) return rt_fail(RT_ERR_INVALID, "image too large for one pass");
+            HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * 12ull)));
+            if (pass_spp < cfg.samples_per_pixel) HIP_TRY(running.alloc((size_t)(n_local_pixels * 12ull)));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel_stream<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel_stream<false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
+        }
+        return RT_OK;
+    }
+
+    int launch(hipStream_t st, float* out) {
+        if (variant == 1) {
+            RenderParams p;
+            p.width = cfg.width; p.height = cfg.height;
+            p.spp = cfg.samples_per_pixel; p.max_depth = cfg.max_depth;
+            p.seed = cfg.seed;
+            p.cam = cam;
+            p.world = scene.dw;
+            p.tm = tm;
+            p.out = out;
+            p.work_counter = work_counter.as<uint32_t>();
+            return launch_render(p, variant, st);
+        }
+        StreamParams p;
+        p.width = cfg.width; p.height = cfg.height;
+        p.spp = cfg.samples_per_pixel; p.max_depth = cfg.max_depth;
+        p.seed = cfg.seed;
+        p.cam = cam;
+        p.tm = tm;
+        p.scene = scene.packed;
+        p.samples = samples.as<float>();
+        p.work_counter = work_counter.as<uint32_t>();
+        uint32_t n_local_pixels = tm.n_local_tiles * RT_TILE * RT_TILE;
+        uint32_t grid = n_cus * stream_blocks_per_cu;
+        for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp) {
+            p.pass_first_s = first;
+            p.pass_spp = std::min(pass_spp, cfg.samples_per_pixel - first);
+            p.total = n_local_pixels * p.pass_spp;
+            HIP_TRY(hipMemsetAsync(work_counter.p, 0, 4, st));
+            if (variant == 2) render_kernel_stream<true><<<grid, RT_STREAM_BLOCK, stream_lds_bytes, st>>>(p);
+            else render_kernel_stream<false><<<grid, RT_STREAM_BLOCK, stream_lds_bytes, st>>>(p);
+            HIP_TRY(hipGetLastError());
+            uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
+            resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
+            HIP_TRY(hipGetLastError());
+        }
+        return RT_OK;
+    }
     ~rt_renderer() {
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -150,6 +321,10 @@ extern "C" int rt_renderer_create(const rt_render_config* cfg, const rt_camera* 
     hipError_t e = r->fb.alloc(fb_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemset(r->fb.p, 0, fb_floats * sizeof(float));
     if (e == hipSuccess) e = r->work_counter.alloc(256);
+    if (e == hipSuccess) {
+        rc = r->plan();
+        if (rc != RT_OK) { delete r; return rc; }
+    }
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&r->ev0);
     if (e == hipSuccess) e = hipEventCreate(&r->ev1);
@@ -167,18 +342,9 @@ extern "C" void rt_renderer_destroy(rt_renderer* r) {
 extern "C" int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float* d_out) {
     if (!r) return rt_fail(RT_ERR_INVALID, "rt_renderer_render_async: null renderer");
     HIP_TRY(hipSetDevice(r->cfg.device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : r->stream;
-    RenderParams p;
-    p.width = r->cfg.width; p.height = r->cfg.height;
-    p.spp = r->cfg.samples_per_pixel; p.max_depth = r->cfg.max_depth;
-    p.seed = r->cfg.seed;
-    p.cam = r->cam;
-    p.world = r->scene.dw;
-    p.tm = r->tm;
-    p.out = d_out ? d_out : r->fb.as<float>();
-    p.work_counter = r->work_counter.as<uint32_t>();
+    hipStream_t st = (hipStream_t)hip_stream;  // NULL is the HIP null stream, as for any HIP launch
     HIP_TRY(hipEventRecord(r->ev0, st));
-    int rc = launch_render(p, r->cfg.variant, st);
+    int rc = r->launch(st, d_out ? d_out : r->fb.as<float>());
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(r->ev1, st));
     r->timed = true;
@@ -186,7 +352,8 @@ extern "C" int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float*
 }
 
 extern "C" int rt_renderer_render(rt_renderer* r) {
-    int rc = rt_renderer_render_async(r, nullptr, nullptr);
+    if (!r) return rt_fail(RT_ERR_INVALID, "rt_renderer_render: null renderer");
+    int rc = rt_renderer_render_async(r, r->stream, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
     return RT_OK;
@@ -232,7 +399,7 @@ __global__ void assemble_kernel(const float4* __restrict__ gathered, float4* __r
 extern "C" int rt_renderer_assemble(rt_renderer* r, const float* d_gathered, float* d_image, void* hip_stream) {
     if (!r || !d_gathered || !d_image) return rt_fail(RT_ERR_INVALID, "rt_renderer_assemble: null argument");
     HIP_TRY(hipSetDevice(r->cfg.device));
-    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : r->stream;
+    hipStream_t st = (hipStream_t)hip_stream;
     uint32_t n = r->cfg.width * r->cfg.height;
     assemble_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float4*)d_gathered, (float4*)d_image, r->tm,
                                                       (uint32_t)(r->shard_floats / 4));

@@ -1,0 +1,299 @@
+// rt_stream_kernel.hpp — the production render path: a persistent, sample-streaming wavefront kernel
+// with the whole BVH resident in LDS, plus the in-order resolve kernel.
+//
+// Reference shape (main/src/Renderer.cu:183-217): one thread per PIXEL, serial spp loop, 48 B of RNG
+// state per pixel in global memory, two virtual calls per bounce, BVH nodes fetched from global memory
+// by pointer.  MI355X shape:
+//
+//  * one work-item owns one pixel-SAMPLE.  The rank's samples of a pass form one linear index space
+//    n = L * pass_spp + s (L = local pixel, tile-major), so the 64 lanes of a wavefront mostly hold
+//    samples of the same pixel (coherent primary rays).  Waves are persistent: each pulls chunks of
+//    RT_CHUNK consecutive sample indices from one global counter and hands them to its lanes with a
+//    ballot + prefix popcount the moment a lane's path ends (sample regeneration), so path-length
+//    divergence (1..50 bounces) does not idle lanes.
+//  * the lane program is the reference's: primary ray, then trace / scatter per bounce with
+//    BVH::ClosestIntersection's exact order of box tests, culling and pushes.  What is re-scheduled is
+//    only WHICH lanes run WHICH phase together: the wave runs "inner node" steps while most lanes sit at
+//    an inner node, services lanes that reached a leaf or finished a trace when enough have piled up
+//    (wave ballots), and never lets one lane's long traversal hold 63 finished ones.
+//  * the scene is staged once per workgroup into LDS (coalesced 16-B loads of one packed blob): 64-B
+//    "wide" inner nodes that carry BOTH child boxes and child references (so a visit is one address, four
+//    ds_read_b128, and leaves need no node fetch at all), 16-B sphere records and 16-B (centre1,
+//    material) records.  The per-lane traversal stack lives in LDS too, sized from the tree's depth.
+//  * the counter-based RNG keeps no state in memory; every sample writes its radiance (12 B) to an HBM
+//    sample buffer laid out [pixel-block][sample][64 pixels], and `resolve_kernel` adds them IN SAMPLE
+//    ORDER per pixel — the same order as the reference's `radiance +=` loop — so the framebuffer is
+//    bit-identical to the CPU oracle's, and independent of scheduling and of the number of GPUs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt06.h"
+#include "rt_device_funcs.hpp"
+#include "rt_internal.hpp"
+#include "rt_render_kernels.hpp"
+
+#define RT_STREAM_BLOCK 512      // 8 wavefronts share one LDS copy of the scene
+#define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
+#define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
+#define RT_SHADE_MIN 16          // run the shade/regenerate phase once this many lanes wait for it
+#define RT_DEFAULT_STREAM_VARIANT 2u  // what rt_render_config::variant == 0 resolves to when the scene fits LDS
+
+// 64-B wide node: both child boxes + both child references.
+// ref >= 0: wide-node index.  ref < 0: leaf, code = -ref - 1 = prim * 2 + is_moving.
+struct WideNode {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    int32_t lref, rref;
+    uint32_t pad[2];
+};
+static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+
+struct PackedSceneRef {
+    const uint4* blob;       // [wide nodes | spheres | extra], 16-B units
+    uint32_t blob_vec4;      // number of 16-B units to stage into LDS
+    uint32_t off_spheres;    // 16-B units
+    uint32_t off_extra;      // 16-B units
+    int32_t root_ref;
+    float root_min[3], root_max[3];
+    uint32_t stack_cap;      // entries per lane
+    const rt_material* mats; // global memory (read once per bounce)
+};
+
+struct StreamParams {
+    uint32_t width, height, spp, max_depth;
+    uint64_t seed;
+    rt_camera cam;
+    TileMap tm;
+    PackedSceneRef scene;
+    uint32_t pass_first_s;   // first sample index of this pass
+    uint32_t pass_spp;       // samples per pixel in this pass
+    uint32_t total;          // n_local_pixels * pass_spp
+    float* samples;          // [n_local_pixels/64][pass_spp][64][3]
+    uint32_t* work_counter;
+};
+
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
+
+// EXACT = true : box tests use aabb_intersects() verbatim (IEEE division, GLM min/max).
+// EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
+//                min/max (rt_fastdiv.hpp); identical results, proven + tested.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(StreamParams p) {
+    extern __shared__ uint4 lds[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+
+    // ---- stage the scene blob: coalesced 16 B per lane --------------------------------------------
+    for (uint32_t i = tid; i < p.scene.blob_vec4; i += RT_STREAM_BLOCK) lds[i] = p.scene.blob[i];
+    __syncthreads();
+
+    const float4* nodes = reinterpret_cast<const float4*>(lds);
+    const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
+    const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
+    int32_t* stack = reinterpret_cast<int32_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
+
+    const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
+    const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
+
+    // ---- per-lane path state ------------------------------------------------------------------------
+    Ray ray;
+    ray.o = mk3(0.0f); ray.d = mk3(0.0f); ray.time = 0.0f;
+    f3 atten = mk3(0.0f);
+    Rng rng;
+    rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
+    float rec_t = RT_MISS_DIST;
+    int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
+    int32_t cur = 0;        // node reference being visited (state ST_TRAV)
+    uint32_t sp = 0;
+    uint32_t depth = 0;
+    uint32_t out_idx = 0;
+    uint32_t state = ST_NEED;
+
+    // ---- wave-uniform work pool ---------------------------------------------------------------------
+    uint32_t pool_next = 0, pool_end = 0;
+    bool pool_dry = false;
+
+    auto begin_trace = [&]() {
+        rec_t = RT_MISS_DIST;
+        rec_code = -1;
+        float d;
+        // BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
+        if (aabb_intersects(root_min, root_max, ray, rec_t, d)) {
+            cur = p.scene.root_ref;
+            sp = 0;
+            state = ST_TRAV;
+        } else {
+            state = ST_SHADE;
+        }
+    };
+    auto pop = [&]() {
+        if (sp == 0) {
+            state = ST_SHADE;
+        } else {
+            sp--;
+            cur = stack[sp * 64u];
+        }
+    };
+    auto emit = [&](f3 rad) {
+        float* o = p.samples + (size_t)out_idx * 3u;
+        o[0] = rad.x; o[1] = rad.y; o[2] = rad.z;
+        state = ST_NEED;
+    };
+
+    for (;;) {
+        // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
+        for (;;) {
+            bool at_inner = (state == ST_TRAV) && (cur >= 0);
+            if (__ballot(at_inner) == 0ull) break;
+            if (at_inner) {
+                const float4* nd = nodes + (uint32_t)cur * 4u;
+                float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+                int32_t left_idx = __float_as_int(q3.x), right_idx = __float_as_int(q3.y);
+                float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                bool hl = aabb_intersects(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, rec_t, left_dist);
+                bool hr = aabb_intersects(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), ray, rec_t, right_dist);
+                // assert that left is closer for next step (BVH.cu:90-93)
+                if (left_dist > right_dist) {
+                    int32_t ti = left_idx; left_idx = right_idx; right_idx = ti;
+                    bool tb = hl; hl = hr; hr = tb;
+                }
+                // push far then near iff dist < rec.distance (BVH.cu:95-96); a hit box has
+                // dist = tmin < rec.distance by aabb.cuh:41, a missed one keeps _MISS_DIST, so the push
+                // conditions ARE the hit flags.  The near child is popped straight away, so it is kept
+                // in `cur` instead of travelling through the stack.
+                if (hl) {
+                    if (hr) { stack[sp * 64u] = right_idx; sp++; }
+                    cur = left_idx;
+                } else if (hr) {
+                    cur = right_idx;
+                } else {
+                    pop();
+                }
+            }
+            bool still = (state == ST_TRAV) && (cur >= 0);
+            if (__popcll(__ballot(still)) < RT_INNER_KEEP) break;
+        }
+
+        // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
+        {
+            bool at_leaf = (state == ST_TRAV) && (cur < 0);
+            if (at_leaf) {
+                uint32_t code = (uint32_t)(-cur - 1);
+                uint32_t prim = code >> 1;
+                float4 sph = spheres[prim];
+                f3 center = mk3(sph.x, sph.y, sph.z);
+                if (code & 1u) {
+                    float4 ex = extra[prim];
+                    center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                }
+                float t = sphere_closest_intersection(ray, center, sph.w);
+                if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
+                    rec_t = t;
+                    rec_code = (int32_t)code;
+                }
+                pop();
+            }
+        }
+
+        // ================= phase 3: shade finished traces, regenerate finished paths ==================
+        uint64_t m_wait = __ballot(state == ST_SHADE || state == ST_NEED);
+        uint64_t m_trav = __ballot(state == ST_TRAV);
+        if (__popcll(m_wait) < RT_SHADE_MIN && m_trav != 0ull) continue;
+
+        if (state == ST_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
+            if (rec_code < 0) {
+                float t = normalize(ray.d).y * 0.5f + 0.5f;
+                f3 sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
+                emit(atten * sky);
+            } else if (depth + 1u >= p.max_depth) {
+                emit(mk3(0.0f));  // the scatter of the last allowed bounce cannot reach the sky: result is 0
+            } else {
+                uint32_t prim = (uint32_t)rec_code >> 1;
+                float4 sph = spheres[prim];
+                float4 ex = extra[prim];
+                f3 center = mk3(sph.x, sph.y, sph.z);
+                if ((uint32_t)rec_code & 1u) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                HitRec rec;
+                rec.distance = rec_t;
+                rec.normal = (ray_at(ray, rec_t) - center) / sph.w;  // SphereHittable.cu:64 / :100
+                rec.prim = (int32_t)prim;
+                rec.mat = __float_as_uint(ex.w);
+                rt_material m = p.scene.mats[rec.mat];
+                Ray scattered;
+                f3 attenuation;
+                if (!material_scatter(m, ray, rec, rng, scattered, attenuation)) {
+                    emit(mk3(0.0f));
+                } else {
+                    atten = atten * attenuation;
+                    ray = scattered;
+                    ray.o = ray.o + ray.d * 0.001f;  // Renderer.cu:175
+                    depth++;
+                    begin_trace();
+                }
+            }
+        }
+
+        // ---- hand new samples to the lanes that need one (wave-uniform loop) -------------------------
+        for (;;) {
+            uint64_t m_need = __ballot(state == ST_NEED);
+            if (m_need == 0ull) break;
+            if (pool_next == pool_end) {
+                if (pool_dry) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(p.work_counter, RT_CHUNK);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= p.total) { pool_dry = true; break; }
+                pool_next = base;
+                pool_end = min(base + RT_CHUNK, p.total);
+            }
+            uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(m_need));
+            uint32_t rank = lane_rank(m_need);
+            if (state == ST_NEED && rank < take) {
+                uint32_t n = pool_next + rank;
+                uint32_t L = n / p.pass_spp;
+                uint32_t s_local = n - L * p.pass_spp;
+                uint32_t gid;
+                if (local_pixel_to_gid(p.tm, L, gid)) {
+                    out_idx = ((L >> 6) * p.pass_spp + s_local) * 64u + (L & 63u);
+                    rng.init(p.seed, gid, p.pass_first_s + s_local, RT_STREAM_RENDER);
+                    ray = primary_ray(p.cam, p.width, p.height, gid, rng);
+                    atten = mk3(1.0f);
+                    depth = 0;
+                    if (p.max_depth == 0u) emit(mk3(0.0f));
+                    else begin_trace();
+                }
+                // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
+            }
+            pool_next += take;
+        }
+        if (pool_dry && state == ST_NEED) state = ST_OFF;
+        if (__ballot(state != ST_OFF) == 0ull) break;
+    }
+}
+
+// Adds the samples of one pass to each pixel IN SAMPLE ORDER (Renderer.cu:198-204: `radiance += ...`),
+// and on the last pass applies mean / clamp / sqrt-gamma / alpha (Renderer.cu:206-216).
+__global__ __launch_bounds__(256) void resolve_kernel(StreamParams p, float* __restrict__ running, float* __restrict__ out, uint32_t last_pass) {
+    uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L >= p.tm.n_local_tiles * RT_TILE * RT_TILE) return;
+    uint32_t gid;
+    if (!local_pixel_to_gid(p.tm, L, gid)) return;
+    f3 radiance = mk3(0.0f);
+    if (p.pass_first_s != 0u) radiance = ld3(running + (size_t)L * 3u);
+    const float* src = p.samples + ((size_t)(L >> 6) * p.pass_spp * 64u + (L & 63u)) * 3u;
+    for (uint32_t s = 0; s < p.pass_spp; s++) {
+        radiance = radiance + ld3(src);
+        src += 64u * 3u;
+    }
+    if (last_pass) {
+        radiance = radiance * (1.0f / (float)p.spp);
+        f3 col = clamp01_sqrt(radiance);
+        reinterpret_cast<float4*>(out)[p.tm.direct ? gid : L] = make_float4(col.x, col.y, col.z, 1.0f);
+    } else {
+        st3(running + (size_t)L * 3u, radiance);
+    }
+}

@@ -266,7 +266,8 @@ def _render_cpu(which, W, H, spp, depth=50, seed=1984):
     return img, cnt
 
 
-VARIANTS = [0, 1]
+VARIANTS = [1, 2]   # 1 = baseline wave-per-pixel kernel, 2 = streaming LDS kernel (+ in-order resolve)
+BIT_EXACT_VARIANTS = {2}  # the streaming path sums samples in the reference's order: image == oracle image
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -286,6 +287,8 @@ def test_framebuffer_matches_oracle(p, which, W, H, spp, variant):
     assert np.nanmax(d) < TOL_SPEC, f"max |delta| {np.nanmax(d)}"
     assert np.nanmax(d) <= TOL_MEASURED, f"max |delta| {np.nanmax(d)} exceeds the summation-order bound"
     assert np.array_equal(np.isnan(img), np.isnan(ref))
+    if variant in BIT_EXACT_VARIANTS:
+        assert bits_equal(img, ref), mismatch_report(img, ref)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -305,6 +308,28 @@ def test_max_depth_is_honoured(p):
     assert np.all(img0[..., :3] == 0.0)  # max bounces exceeded -> black (Renderer.cu:178-180)
 
 
+def _sparse_gids(img, rng, n):
+    """n random pixels plus EVERY non-finite pixel of the GPU image.  A NaN pixel is legitimate: the
+    reference's dielectric returns a zero direction when `refract`'s k < 0 disagrees by one rounding with
+    the `ior_ratio * sin_theta > 1` test (cu_materials.cuh:133-137, func_geometric.inl:117-120), and the
+    sky term then normalises a zero vector (Renderer.cu:150).  At ~1e-9 per sample it shows up only in
+    full-size frames; the oracle must produce NaN at exactly the same pixels."""
+    H, W = img.shape[:2]
+    bad = np.argwhere(~np.isfinite(img[..., :3]).all(axis=2))
+    assert len(bad) <= 16, f"{len(bad)} non-finite pixels"
+    extra = (bad[:, 0] * W + bad[:, 1]).astype(np.uint32)
+    fin = img[np.isfinite(img)]
+    assert fin.min() >= 0.0 and fin.max() <= 1.0
+    return np.concatenate([rng.integers(0, W * H, n).astype(np.uint32), extra])
+
+
+def _check_sparse(got, exp):
+    assert np.array_equal(np.isnan(got), np.isnan(exp)), "NaN pixels differ between GPU and oracle"
+    d = float(np.nanmax(np.abs(got - exp)))
+    assert d < TOL_SPEC and d <= TOL_MEASURED, d
+    return d
+
+
 @pytest.mark.parametrize("variant", VARIANTS)
 def test_full_size_config2_properties(p, variant):
     """BASELINE.json configs[1] at FULL size (1200x800, 500 spp = 4.8e8 samples) through properties:
@@ -315,15 +340,15 @@ def test_full_size_config2_properties(p, variant):
     img2, _ = _render_gpu(p, "book1_final", W, H, spp, variant=variant)
     assert img.tobytes() == img2.tobytes(), "render is not deterministic"
     assert np.all(img[..., 3] == 1.0)
-    assert np.isfinite(img).all() and img.min() >= 0.0 and img.max() <= 1.0
     rng = np.random.default_rng(11)
-    gids = rng.integers(0, W * H, 192).astype(np.uint32)
+    gids = _sparse_gids(img, rng, 192)
     o = oracle_scene("book1_final")
     oc = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
     exp = O.render_pixels(o.world, oc, W, H, spp, 50, gids)
     got = img.reshape(-1, 4)[gids]
-    d = np.abs(got - exp).max()
-    assert d < TOL_SPEC and d <= TOL_MEASURED, d
+    d = _check_sparse(got, exp)
+    if variant in BIT_EXACT_VARIANTS:
+        assert bits_equal(got, exp), mismatch_report(got, exp)
     print(f"config2 full size variant {variant}: {W*H*spp/ms/1e3:.1f} Msamples/s ({ms:.1f} ms), max|delta| on 192 px = {d:.2e}")
 
 
@@ -332,13 +357,15 @@ def test_full_size_config3_sparse_parity(p):
     W, H, spp = 800, 800, 1000
     img, ms = _render_gpu(p, "book2_moving", W, H, spp)
     rng = np.random.default_rng(12)
-    gids = rng.integers(0, W * H, 96).astype(np.uint32)
+    gids = _sparse_gids(img, rng, 96)
     o = oracle_scene("book2_moving")
     oc = O.camera_motion((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.0, 1.0)
     exp = O.render_pixels(o.world, oc, W, H, spp, 50, gids)
-    d = np.abs(img.reshape(-1, 4)[gids] - exp).max()
-    assert d <= TOL_MEASURED, d
-    assert np.all(img[..., 3] == 1.0) and img.min() >= 0.0 and img.max() <= 1.0
+    got = img.reshape(-1, 4)[gids]
+    _check_sparse(got, exp)
+    assert bits_equal(got, exp), mismatch_report(got, exp)  # default variant = streaming path
+    assert np.all(img[..., 3] == 1.0)
+    print(f"config3 full size: {W*H*spp/ms/1e3:.1f} Msamples/s ({ms:.1f} ms)")
 
 
 @pytest.mark.parametrize("world_size", [2, 3, 8])
@@ -384,3 +411,23 @@ def test_bad_world_is_refused_not_faulted(p):
         p.Renderer.MakeRenderer(64, 64, 1, 4, cam, w)
     with pytest.raises(p.capi.RtError, match="must be > 0"):
         p.Renderer.MakeRenderer(0, 64, 1, 4, cam, s.getWorldPtr())
+
+
+def test_multi_pass_rendering_is_bit_identical(p, monkeypatch):
+    """When spp does not fit the per-pass sample buffer the frame is rendered in several passes; the
+    resolve kernel carries the running sum in sample order, so the image must not change by one bit."""
+    W, H, spp = 96, 64, 37
+    s = config_scene(p, "book2_moving")
+    cam = config_cameras(p, "book2_moving", W, H)
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr(), variant=2)
+    r.Render()
+    one = r.DownloadRenderbuffer()
+    r.close()
+    monkeypatch.setenv("RT06_PASS_BUDGET_BYTES", str(W * H * 12 * 5))  # 5 samples per pixel per pass -> 8 passes
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr(), variant=2)
+    r.Render()
+    many = r.DownloadRenderbuffer()
+    r.close()
+    assert one.tobytes() == many.tobytes()
+    ref, _ = _render_cpu("book2_moving", W, H, spp)
+    assert bits_equal(one, ref), mismatch_report(one, ref)
