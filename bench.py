@@ -47,12 +47,24 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPUs this process may actually use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
     """cpu_baseline + algorithmic counts + parity sample, rank 0 at N == 1 only.  The oracle is the checker
     and the timed baseline here; it is never on the product path."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     W, H = args.width, args.height
     oscene = O.Scene.book1_final(args.seed)
     ocam = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)

@@ -79,6 +79,26 @@ def build_native(force=False):
     return LIB_PATH
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so with the same SONAME as /opt/rocm's.  A process
+    must run on ONE HIP runtime, and torch only works on its own, so when torch is installed its copy is
+    loaded first (without importing torch); librt06.so's libamdhip64.so.7 dependency then binds to it and
+    device pointers / streams can be shared with torch whichever of the two is imported first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -86,6 +106,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the render path.")
+    _preload_torch_hip_runtime()
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.rt_last_error.restype = C.c_char_p

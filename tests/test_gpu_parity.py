@@ -279,6 +279,8 @@ BIT_EXACT_VARIANTS = {2}  # the streaming path sums samples in the reference's o
     ("book2_moving", 200, 200, 24),    # configs[2] scene, reduced
 ])
 def test_framebuffer_matches_oracle(p, which, W, H, spp, variant):
+    if which == "three_spheres" and variant == 2:
+        pytest.skip("the streaming kernel takes RT_WORLD_BVH worlds; a HittableList renders on the baseline kernel")
     img, _ = _render_gpu(p, which, W, H, spp, variant=variant)
     ref, _ = _render_cpu(which, W, H, spp)
     assert img.shape == ref.shape == (H, W, 4)
