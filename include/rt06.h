@@ -262,6 +262,18 @@ int rt_probe_sphere_index(int device, const rt_camera* cam, uint32_t width, uint
 /* raw uniforms of the counter-based RNG: keys n*2, n_draws each -> n*n_draws */
 int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t* keys, uint32_t n_draws, float* out);
 
+/* Verification probes for the fast exact division of the streaming kernel (csrc/rt_fastdiv.hpp).
+ * rt_probe_aabb_regular: boxes n*6, rays n*6, max_dist n -> the "regular ray" classification n, and
+ * hit/dist of the 5-instruction-division box test (only meaningful where regular == 1).             */
+int rt_probe_aabb_regular(int device, size_t n, const float* boxes, const float* rays, const float* max_dist,
+                          int32_t* out_regular, int32_t* out_hit, float* out_dist);
+/* Exhaustive self-test: for each of n_den divisor significands starting at first_den (0 .. 2^23-1) and
+ * ALL 2^23 numerator significands, compare the 5-instruction quotient with IEEE n/d bit for bit.
+ * num_exp / den_exp are the unbiased exponents given to numerator and divisor.  Returns the number of
+ * mismatching pairs in *mismatches and one example in example[2] (numerator, divisor bits).          */
+int rt_selftest_fastdiv(int device, uint32_t first_den, uint32_t n_den, int32_t num_exp, int32_t den_exp,
+                        uint64_t* mismatches, uint32_t example[2]);
+
 /* library / device info */
 int rt_device_count(int* out);
 const char* rt_version(void);

@@ -273,3 +273,19 @@ def device_count():
     n = C.c_int()
     check(lib().rt_device_count(C.byref(n)))
     return n.value
+
+
+def probe_aabb_regular(boxes, rays, max_dist, device=0):
+    n = len(boxes)
+    reg = np.zeros(n, np.int32); hit = np.zeros(n, np.int32); dist = np.zeros(n, np.float32)
+    check(lib().rt_probe_aabb_regular(device, n, np.ascontiguousarray(boxes, np.float32), np.ascontiguousarray(rays, np.float32),
+                                      np.ascontiguousarray(max_dist, np.float32), reg, hit, dist))
+    return reg, hit, dist
+
+
+def selftest_fastdiv(first_den, n_den, num_exp=0, den_exp=0, device=0):
+    """(mismatching pairs, example) over n_den divisor significands x all 2^23 numerator significands."""
+    bad = C.c_uint64()
+    ex = np.zeros(2, np.uint32)
+    check(lib().rt_selftest_fastdiv(device, first_den, n_den, num_exp, den_exp, C.byref(bad), ex))
+    return bad.value, ex

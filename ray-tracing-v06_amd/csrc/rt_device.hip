@@ -56,6 +56,7 @@ struct DeviceScene {
     PackedSceneRef packed{};  // valid when has_packed
     bool has_packed = false;
     uint32_t true_stack = 0;  // traversal-stack bound computed from the tree itself
+    bool regular_boxes = false;  // all box coordinates inside the fast-division class
 
     // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 64-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
@@ -103,6 +104,11 @@ struct DeviceScene {
         for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
         packed.stack_cap = true_stack ? true_stack : 1u;
         packed.mats = mats.as<rt_material>();
+        // rt_fastdiv.hpp condition (a): every box coordinate is 0 or 2^-40 <= |b| < 2^40
+        regular_boxes = true;
+        for (uint32_t i = 0; i < w->n_nodes && regular_boxes; i++)
+            for (int k = 0; k < 3; k++)
+                if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k])) regular_boxes = false;
         has_packed = true;
         return RT_OK;
     }
@@ -225,9 +231,11 @@ struct rt_renderer {
             if (stream_lds_bytes > lds_per_cu) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
-        if (want == 0) want = can_stream ? RT_DEFAULT_STREAM_VARIANT : 1u;
+        if (want == 0) want = can_stream ? (scene.regular_boxes ? 3u : 2u) : 1u;
         if (want >= 2 && !can_stream)
             return rt_fail(RT_ERR_INVALID, "kernel variant %u needs an RT_WORLD_BVH world whose LDS image fits in 160 KiB", want);
+        if (want == 3 && !scene.regular_boxes)
+            return rt_fail(RT_ERR_INVALID, "kernel variant 3 needs every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
         if (variant >= 2) {
             uint64_t budget = 8ull << 30;  // HBM for one pass of per-sample radiance (12 B each)
@@ -632,5 +640,82 @@ extern "C" int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t*
     probe_rng_kernel<<<PROBE_GRID(n)>>>(seed, n, k.as<uint32_t>(), n_draws, o.as<float>());
     FINISH();
     DOWN(out, o, n * n_draws * 4);
+    return RT_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// verification of rt_fastdiv.hpp
+// ---------------------------------------------------------------------------------------------
+__global__ void probe_aabb_regular_kernel(size_t n, const float* boxes, const float* rays, const float* maxd, int32_t* regular,
+                                          int32_t* hit, float* dist) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = ld3(rays + 6 * i); r.d = ld3(rays + 6 * i + 3); r.time = 0.0f;
+    f3 bmin = ld3(boxes + 6 * i), bmax = ld3(boxes + 6 * i + 3);
+    bool reg = ray_is_regular(r) && coord_is_regular(bmin.x) && coord_is_regular(bmin.y) && coord_is_regular(bmin.z) &&
+               coord_is_regular(bmax.x) && coord_is_regular(bmax.y) && coord_is_regular(bmax.z);
+    regular[i] = reg ? 1 : 0;
+    float d = 0.0f;
+    bool h = false;
+    if (reg) {
+        f3 inv_d = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        h = aabb_intersects_regular(bmin, bmax, r, inv_d, maxd[i], d);
+    }
+    hit[i] = h ? 1 : 0;
+    dist[i] = d;
+}
+
+extern "C" int rt_probe_aabb_regular(int device, size_t n, const float* boxes, const float* rays, const float* max_dist,
+                                     int32_t* out_regular, int32_t* out_hit, float* out_dist) {
+    if (!boxes || !rays || !max_dist || !out_regular || !out_hit || !out_dist) return rt_fail(RT_ERR_INVALID, "rt_probe_aabb_regular: null argument");
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf b, r, m, g, h, d;
+    UP(b, boxes, n * 24); UP(r, rays, n * 24); UP(m, max_dist, n * 4);
+    HIP_TRY(g.alloc(n * 4)); HIP_TRY(h.alloc(n * 4)); HIP_TRY(d.alloc(n * 4));
+    probe_aabb_regular_kernel<<<PROBE_GRID(n)>>>(n, b.as<float>(), r.as<float>(), m.as<float>(), g.as<int32_t>(), h.as<int32_t>(), d.as<float>());
+    FINISH();
+    DOWN(out_regular, g, n * 4); DOWN(out_hit, h, n * 4); DOWN(out_dist, d, n * 4);
+    return RT_OK;
+}
+
+// one block per divisor significand; its 256 threads sweep all 2^23 numerator significands
+__global__ __launch_bounds__(256) void selftest_fastdiv_kernel(uint32_t first_den, uint32_t num_exp_bits, uint32_t den_exp_bits,
+                                                               unsigned long long* mismatches, uint32_t* example) {
+    uint32_t md = first_den + blockIdx.x;
+    float d = __uint_as_float(den_exp_bits | md);
+    float r = 1.0f / d;
+    uint32_t bad = 0;
+    uint32_t bad_n = 0;
+    for (uint32_t mn = threadIdx.x; mn < (1u << 23); mn += 256u) {
+        float n = __uint_as_float(num_exp_bits | mn);
+        float q = fast_div_exact(n, d, r);
+        float ref = n / d;
+        if (__float_as_uint(q) != __float_as_uint(ref)) { bad++; bad_n = __float_as_uint(n); }
+    }
+    if (bad) {
+        atomicAdd(mismatches, (unsigned long long)bad);
+        example[0] = bad_n;
+        example[1] = __float_as_uint(d);
+    }
+}
+
+extern "C" int rt_selftest_fastdiv(int device, uint32_t first_den, uint32_t n_den, int32_t num_exp, int32_t den_exp,
+                                   uint64_t* mismatches, uint32_t example[2]) {
+    if (!mismatches || !example) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastdiv: null argument");
+    if (first_den >= (1u << 23) || n_den == 0 || n_den > (1u << 23) - first_den) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastdiv: significand range out of bounds");
+    if (num_exp < -126 || num_exp > 127 || den_exp < -126 || den_exp > 127) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastdiv: exponent out of range");
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf cnt, ex;
+    HIP_TRY(cnt.alloc(8)); HIP_TRY(ex.alloc(8));
+    HIP_TRY(hipMemset(cnt.p, 0, 8)); HIP_TRY(hipMemset(ex.p, 0, 8));
+    selftest_fastdiv_kernel<<<n_den, 256>>>(first_den, (uint32_t)(num_exp + 127) << 23, (uint32_t)(den_exp + 127) << 23,
+                                            cnt.as<unsigned long long>(), ex.as<uint32_t>());
+    FINISH();
+    DOWN(mismatches, cnt, 8); DOWN(example, ex, 8);
     return RT_OK;
 }

@@ -162,31 +162,33 @@ RT_HD float reflectance(float cos_theta, float ior_ratio) {
 }
 
 // checker_texture::value, rt_engine/shaders/cu_Textures.cuh:31-39 (ivec3 truncates toward zero)
-RT_HD f3 checker_value(const rt_material& m, f3 pos) {
-    f3 sp = pos * m.param;
+RT_HD f3 checker_value(f3 even, f3 odd, float inv_scale, f3 pos) {
+    f3 sp = pos * inv_scale;
     int ix = (int)sp.x, iy = (int)sp.y, iz = (int)sp.z;
     int sum = 0;
     sum += ix; sum += iy; sum += iz;
-    return (sum % 2 == 0) ? mk3(m.albedo[0], m.albedo[1], m.albedo[2]) : mk3(m.albedo2[0], m.albedo2[1], m.albedo2[2]);
+    bool is_even = (sum % 2 == 0);
+    return mk3(is_even ? even.x : odd.x, is_even ? even.y : odd.y, is_even ? even.z : odd.z);
 }
 
 // Material::Scatter — LambertianAbstract (cu_materials.cuh:52-64), MetalAbstract (:77-95),
 // DielectricAbstract (:115-143), LambertianTexture (:27-40)
 RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRec& rec, Rng& rng, Ray& out, f3& attenuation) {
     f3 normal = rec.normal;
+    const f3 albedo = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    const f3 albedo2 = mk3(m.albedo2[0], m.albedo2[1], m.albedo2[2]);
     if (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LAMBERTIAN_CHECKER) {
         f3 ray_dir = normal + rng_on_unit3(rng);
         if (near_zero(ray_dir)) return false;
         out.o = ray_at(in_ray, rec.distance); out.d = ray_dir; out.time = in_ray.time;
-        attenuation = (m.type == RT_MAT_LAMBERTIAN) ? mk3(m.albedo[0], m.albedo[1], m.albedo[2])
-                                                    : checker_value(m, ray_at(in_ray, rec.distance));
+        attenuation = (m.type == RT_MAT_LAMBERTIAN) ? albedo : checker_value(albedo, albedo2, m.param, ray_at(in_ray, rec.distance));
         return true;
     }
     if (m.type == RT_MAT_METAL) {
         f3 scatter_dir = reflect(in_ray.d, normal) + rng_on_unit3(rng) * m.param;
         if (dot(scatter_dir, normal) < 0 || near_zero(scatter_dir)) return false;
         out.o = ray_at(in_ray, rec.distance); out.d = scatter_dir; out.time = in_ray.time;
-        attenuation = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+        attenuation = albedo;
         return true;
     }
     float ior = m.param;
@@ -201,7 +203,7 @@ RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRe
     if (ior_ratio * sin_theta > 1.0f || reflect_prob > rng.next()) scatter_dir = reflect(unit_dir, normal);
     else scatter_dir = refract(unit_dir, normal, ior_ratio);
     out.o = ray_at(in_ray, rec.distance); out.d = scatter_dir; out.time = in_ray.time;
-    attenuation = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    attenuation = albedo;
     return true;
 }
 

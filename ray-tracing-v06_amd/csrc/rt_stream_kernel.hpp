@@ -6,8 +6,9 @@
 // by pointer.  MI355X shape:
 //
 //  * one work-item owns one pixel-SAMPLE.  The rank's samples of a pass form one linear index space
-//    n = L * pass_spp + s (L = local pixel, tile-major), so the 64 lanes of a wavefront mostly hold
-//    samples of the same pixel (coherent primary rays).  Waves are persistent: each pulls chunks of
+//    n = (block * pass_spp + s) * 64 + pixel-in-block (a block = the 64 pixels of an 8x8 tile), so the
+//    64 lanes of a wavefront mostly hold one sample each of the 64 pixels of a tile (coherent primary
+//    rays) and n is also the slot of the sample in the HBM sample buffer.  Waves are persistent: each pulls chunks of
 //    RT_CHUNK consecutive sample indices from one global counter and hands them to its lanes with a
 //    ballot + prefix popcount the moment a lane's path ends (sample regeneration), so path-length
 //    divergence (1..50 bounces) does not idle lanes.
@@ -29,6 +30,7 @@
 
 #include "rt06.h"
 #include "rt_device_funcs.hpp"
+#include "rt_fastdiv.hpp"
 #include "rt_internal.hpp"
 #include "rt_render_kernels.hpp"
 
@@ -36,7 +38,6 @@
 #define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
 #define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
 #define RT_SHADE_MIN 16          // run the shade/regenerate phase once this many lanes wait for it
-#define RT_DEFAULT_STREAM_VARIANT 2u  // what rt_render_config::variant == 0 resolves to when the scene fits LDS
 
 // 64-B wide node: both child boxes + both child references.
 // ref >= 0: wide-node index.  ref < 0: leaf, code = -ref - 1 = prim * 2 + is_moving.
@@ -79,7 +80,8 @@ enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
 
 // EXACT = true : box tests use aabb_intersects() verbatim (IEEE division, GLM min/max).
 // EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
-//                min/max (rt_fastdiv.hpp); identical results, proven + tested.
+//                min/max (rt_fastdiv.hpp) — identical decisions, proven + exhaustively verified; other
+//                rays take the verbatim path lane by lane.
 template <bool EXACT>
 __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
@@ -98,10 +100,13 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
+    const uint32_t samples_per_block = 64u * p.pass_spp;  // sample indices per 64-pixel block
 
     // ---- per-lane path state ------------------------------------------------------------------------
     Ray ray;
     ray.o = mk3(0.0f); ray.d = mk3(0.0f); ray.time = 0.0f;
+    f3 inv_d = mk3(0.0f);   // RN(1/d) of a regular ray (EXACT == false)
+    bool regular = false;
     f3 atten = mk3(0.0f);
     Rng rng;
     rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
@@ -110,39 +115,46 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
     int32_t cur = 0;        // node reference being visited (state ST_TRAV)
     uint32_t sp = 0;
     uint32_t depth = 0;
-    uint32_t out_idx = 0;
+    uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
     uint32_t state = ST_NEED;
 
     // ---- wave-uniform work pool ---------------------------------------------------------------------
     uint32_t pool_next = 0, pool_end = 0;
     bool pool_dry = false;
 
-    auto begin_trace = [&]() {
-        rec_t = RT_MISS_DIST;
-        rec_code = -1;
-        float d;
-        // BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
-        if (aabb_intersects(root_min, root_max, ray, rec_t, d)) {
-            cur = p.scene.root_ref;
-            sp = 0;
-            state = ST_TRAV;
-        } else {
-            state = ST_SHADE;
-        }
-    };
-    auto pop = [&]() {
-        if (sp == 0) {
-            state = ST_SHADE;
-        } else {
-            sp--;
-            cur = stack[sp * 64u];
-        }
-    };
-    auto emit = [&](f3 rad) {
-        float* o = p.samples + (size_t)out_idx * 3u;
-        o[0] = rad.x; o[1] = rad.y; o[2] = rad.z;
-        state = ST_NEED;
-    };
+// BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
+#define RT_BEGIN_TRACE()                                                   \
+    do {                                                                   \
+        rec_t = RT_MISS_DIST;                                              \
+        rec_code = -1;                                                     \
+        if (!EXACT) {                                                      \
+            regular = ray_is_regular(ray);                                 \
+            inv_d = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);   \
+        }                                                                  \
+        float d_root_;                                                     \
+        if (aabb_intersects(root_min, root_max, ray, rec_t, d_root_)) {    \
+            cur = p.scene.root_ref;                                        \
+            sp = 0;                                                        \
+            state = ST_TRAV;                                               \
+        } else {                                                           \
+            state = ST_SHADE;                                              \
+        }                                                                  \
+    } while (0)
+#define RT_POP()                      \
+    do {                              \
+        if (sp == 0) {                \
+            state = ST_SHADE;         \
+        } else {                      \
+            sp--;                     \
+            cur = stack[sp * 64u];    \
+        }                             \
+    } while (0)
+#define RT_EMIT(rx, ry, rz)                                   \
+    do {                                                      \
+        float* o_ = p.samples + (size_t)out_idx * 3u;         \
+        o_[0] = (rx); o_[1] = (ry); o_[2] = (rz);             \
+        state = ST_NEED;                                      \
+    } while (0)
 
     for (;;) {
         // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
@@ -154,8 +166,14 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 int32_t left_idx = __float_as_int(q3.x), right_idx = __float_as_int(q3.y);
                 float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                bool hl = aabb_intersects(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, rec_t, left_dist);
-                bool hr = aabb_intersects(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), ray, rec_t, right_dist);
+                bool hl, hr;
+                if (EXACT || !regular) {
+                    hl = aabb_intersects(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, rec_t, left_dist);
+                    hr = aabb_intersects(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), ray, rec_t, right_dist);
+                } else {
+                    hl = aabb_intersects_regular(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, inv_d, rec_t, left_dist);
+                    hr = aabb_intersects_regular(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), ray, inv_d, rec_t, right_dist);
+                }
                 // assert that left is closer for next step (BVH.cu:90-93)
                 if (left_dist > right_dist) {
                     int32_t ti = left_idx; left_idx = right_idx; right_idx = ti;
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 } else if (hr) {
                     cur = right_idx;
                 } else {
-                    pop();
+                    RT_POP();
                 }
             }
             bool still = (state == ST_TRAV) && (cur >= 0);
@@ -179,24 +197,21 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
         }
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
-        {
-            bool at_leaf = (state == ST_TRAV) && (cur < 0);
-            if (at_leaf) {
-                uint32_t code = (uint32_t)(-cur - 1);
-                uint32_t prim = code >> 1;
-                float4 sph = spheres[prim];
-                f3 center = mk3(sph.x, sph.y, sph.z);
-                if (code & 1u) {
-                    float4 ex = extra[prim];
-                    center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
-                }
-                float t = sphere_closest_intersection(ray, center, sph.w);
-                if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
-                    rec_t = t;
-                    rec_code = (int32_t)code;
-                }
-                pop();
+        if ((state == ST_TRAV) && (cur < 0)) {
+            uint32_t code = (uint32_t)(-cur - 1);
+            uint32_t prim = code >> 1;
+            float4 sph = spheres[prim];
+            f3 center = mk3(sph.x, sph.y, sph.z);
+            if (code & 1u) {
+                float4 ex = extra[prim];
+                center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
             }
+            float t = sphere_closest_intersection(ray, center, sph.w);
+            if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
+                rec_t = t;
+                rec_code = (int32_t)code;
+            }
+            RT_POP();
         }
 
         // ================= phase 3: shade finished traces, regenerate finished paths ==================
@@ -208,9 +223,10 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
             if (rec_code < 0) {
                 float t = normalize(ray.d).y * 0.5f + 0.5f;
                 f3 sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
-                emit(atten * sky);
+                f3 rad = atten * sky;
+                RT_EMIT(rad.x, rad.y, rad.z);
             } else if (depth + 1u >= p.max_depth) {
-                emit(mk3(0.0f));  // the scatter of the last allowed bounce cannot reach the sky: result is 0
+                RT_EMIT(0.0f, 0.0f, 0.0f);  // the scatter of the last allowed bounce cannot reach the sky: result is 0
             } else {
                 uint32_t prim = (uint32_t)rec_code >> 1;
                 float4 sph = spheres[prim];
@@ -222,17 +238,21 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 rec.normal = (ray_at(ray, rec_t) - center) / sph.w;  // SphereHittable.cu:64 / :100
                 rec.prim = (int32_t)prim;
                 rec.mat = __float_as_uint(ex.w);
-                rt_material m = p.scene.mats[rec.mat];
+                const float4* mp = reinterpret_cast<const float4*>(p.scene.mats + rec.mat);
+                float4 m0 = mp[0], m1 = mp[1];
+                rt_material m;
+                m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
+                m.albedo2[0] = m1.x; m.albedo2[1] = m1.y; m.albedo2[2] = m1.z; m.type = __float_as_uint(m1.w);
                 Ray scattered;
                 f3 attenuation;
                 if (!material_scatter(m, ray, rec, rng, scattered, attenuation)) {
-                    emit(mk3(0.0f));
+                    RT_EMIT(0.0f, 0.0f, 0.0f);
                 } else {
                     atten = atten * attenuation;
                     ray = scattered;
                     ray.o = ray.o + ray.d * 0.001f;  // Renderer.cu:175
                     depth++;
-                    begin_trace();
+                    RT_BEGIN_TRACE();
                 }
             }
         }
@@ -253,18 +273,21 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
             uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(m_need));
             uint32_t rank = lane_rank(m_need);
             if (state == ST_NEED && rank < take) {
+                // sample index n -> (64-pixel block, sample, pixel in block): [block][sample][pixel]
                 uint32_t n = pool_next + rank;
-                uint32_t L = n / p.pass_spp;
-                uint32_t s_local = n - L * p.pass_spp;
+                uint32_t blk = n / samples_per_block;
+                uint32_t rem = n - blk * samples_per_block;
+                uint32_t s_local = rem >> 6;
+                uint32_t L = blk * 64u + (rem & 63u);
                 uint32_t gid;
                 if (local_pixel_to_gid(p.tm, L, gid)) {
-                    out_idx = ((L >> 6) * p.pass_spp + s_local) * 64u + (L & 63u);
+                    out_idx = n;
                     rng.init(p.seed, gid, p.pass_first_s + s_local, RT_STREAM_RENDER);
                     ray = primary_ray(p.cam, p.width, p.height, gid, rng);
                     atten = mk3(1.0f);
                     depth = 0;
-                    if (p.max_depth == 0u) emit(mk3(0.0f));
-                    else begin_trace();
+                    if (p.max_depth == 0u) RT_EMIT(0.0f, 0.0f, 0.0f);
+                    else RT_BEGIN_TRACE();
                 }
                 // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
             }
@@ -273,6 +296,9 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
         if (pool_dry && state == ST_NEED) state = ST_OFF;
         if (__ballot(state != ST_OFF) == 0ull) break;
     }
+#undef RT_BEGIN_TRACE
+#undef RT_POP
+#undef RT_EMIT
 }
 
 // Adds the samples of one pass to each pixel IN SAMPLE ORDER (Renderer.cu:198-204: `radiance += ...`),

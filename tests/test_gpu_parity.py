@@ -266,8 +266,8 @@ def _render_cpu(which, W, H, spp, depth=50, seed=1984):
     return img, cnt
 
 
-VARIANTS = [1, 2]   # 1 = baseline wave-per-pixel kernel, 2 = streaming LDS kernel (+ in-order resolve)
-BIT_EXACT_VARIANTS = {2}  # the streaming path sums samples in the reference's order: image == oracle image
+VARIANTS = [1, 2, 3]   # 1 = baseline wave-per-pixel kernel, 2 = streaming LDS kernel, 3 = streaming + fast exact division
+BIT_EXACT_VARIANTS = {2, 3}  # the streaming path sums samples in the reference's order: image == oracle image
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -279,7 +279,7 @@ BIT_EXACT_VARIANTS = {2}  # the streaming path sums samples in the reference's o
     ("book2_moving", 200, 200, 24),    # configs[2] scene, reduced
 ])
 def test_framebuffer_matches_oracle(p, which, W, H, spp, variant):
-    if which == "three_spheres" and variant == 2:
+    if which == "three_spheres" and variant >= 2:
         pytest.skip("the streaming kernel takes RT_WORLD_BVH worlds; a HittableList renders on the baseline kernel")
     img, _ = _render_gpu(p, which, W, H, spp, variant=variant)
     ref, _ = _render_cpu(which, W, H, spp)
@@ -433,3 +433,46 @@ def test_multi_pass_rendering_is_bit_identical(p, monkeypatch):
     assert one.tobytes() == many.tobytes()
     ref, _ = _render_cpu("book2_moving", W, H, spp)
     assert bits_equal(one, ref), mismatch_report(one, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# the 5-instruction correctly rounded division of the streaming kernel (csrc/rt_fastdiv.hpp)
+# ------------------------------------------------------------------------------------------------
+def test_fastdiv_matches_ieee_division(p):
+    """q2 == n/d bit for bit: 64 divisor significands (incl. the all-ones and power-of-two ones) x ALL 2^23
+    numerator significands, at the centre and at the corners of the regular class's exponent range.
+    tools/verify_fastdiv.py sweeps every divisor significand (2^46 pairs); result in profiles/."""
+    rng = np.random.default_rng(21)
+    special = [0, 1, 2, 3, (1 << 23) - 1, (1 << 23) - 2, 1 << 22, (1 << 22) - 1, (1 << 22) + 1, 0x2AAAAA, 0x555555]
+    firsts = special + rng.integers(0, 1 << 23, 53).tolist()
+    total = 0
+    for k, first in enumerate(firsts):
+        ne, de = [(0, 0), (-64, 39), (40, -40), (-64, -40), (40, 39)][k % 5]
+        bad, ex = p.api.selftest_fastdiv(int(first), 1, ne, de)
+        assert bad == 0, f"divisor significand {first:#x}: {bad} mismatches, e.g. n={ex[0]:#x} d={ex[1]:#x}"
+        total += 1 << 23
+    assert total == 64 << 23
+
+
+def test_box_test_with_fast_division_makes_identical_decisions(p):
+    """aabb_intersects_regular vs aabb::intersects on regular rays: same hit flag and same dist."""
+    rng = np.random.default_rng(22)
+    n = 1 << 18
+    lo = (rng.random((n, 3), dtype=np.float32) * 2 - 1) * 12
+    ext = rng.random((n, 3), dtype=np.float32) * 3
+    boxes = np.concatenate([lo, lo + ext], axis=1).astype(np.float32)
+    boxes[: n // 8, 1] = 0.0  # exact-zero coordinates (ground-level boxes), like the book scenes
+    rays = random_rays(rng, n, with_time=False)
+    rays[n // 2:, 0:3] = lo[n // 2:] + ext[n // 2:] * rng.random((n // 2, 3), dtype=np.float32) * 1.5  # near / inside the box
+    rays[: n // 16, 3] *= np.float32(1e-6)   # near axis-parallel but still regular
+    rays[n // 16: n // 8, 4] = 0.0           # irregular: exact zero direction component
+    maxd = np.where(rng.random(n) < 0.5, np.float32(3.402823466e38), rng.random(n, dtype=np.float32) * 30).astype(np.float32)
+    reg, hit, dist = p.api.probe_aabb_regular(boxes, rays, maxd)
+    ehit = np.zeros(n, np.int32); edist = np.zeros(n, np.float32)
+    O.lib().orc_aabb_batch(n, boxes, rays, maxd, ehit, edist)
+    m = reg == 1
+    assert 0.8 < m.mean() < 0.99 and not reg[n // 16: n // 8].any()
+    assert np.array_equal(hit[m], ehit[m])
+    # dist may differ in the sign of a zero only (IEEE min/max vs GLM's (y<x)?y:x)
+    assert np.array_equal(dist[m] + np.float32(0.0), edist[m] + np.float32(0.0))
+    assert bits_equal(np.abs(dist[m]), np.abs(edist[m]))
