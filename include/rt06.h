@@ -244,11 +244,11 @@ int rt_probe_trace(int device, const rt_world_flat* world, size_t n, const float
                    int32_t* out_hit, float* out_t, int32_t* out_prim, float* out_normal);
 /* Material::Scatter (cu_materials.cuh:52,77,115,27): per case a material,
  * in-ray n*7, hit distance n, outward normal n*3, RNG key (pixel,sample) n*2
- * -> scattered n (0/1), out ray n*7, attenuation n*3, draws consumed n       */
+ * -> scattered n (0/1), out ray n*7, attenuation n*3, RNG blocks consumed n  */
 int rt_probe_scatter(int device, uint64_t seed, size_t n, const rt_material* mats, const float* rays,
                      const float* dist, const float* normals, const uint32_t* keys,
                      int32_t* out_scattered, float* out_rays, float* out_atten, uint32_t* out_draws);
-/* camera sample_ray (cu_Cameras.cuh:27,54,87): st n*2, keys n*2 -> ray n*7   */
+/* camera sample_ray (cu_Cameras.cuh:27,54,87): st n*2, keys n*2 -> ray n*7, RNG blocks consumed n */
 int rt_probe_camera(int device, uint64_t seed, const rt_camera* cam, size_t n, const float* st,
                     const uint32_t* keys, float* out_rays, uint32_t* out_draws);
 /* one full sample (render_kernel body for one s + sample_world,

@@ -75,7 +75,8 @@ struct DeviceScene {
             return -(int32_t)code - 1;
         };
         if (w->n_prims >= (1u << 29)) return RT_OK;  // leaf code would not fit
-        size_t n_vec4 = (size_t)n_inner * 4 + (size_t)w->n_prims * 2;
+        if (w->n_materials >= (1u << 30)) return RT_OK;
+        size_t n_vec4 = (size_t)n_inner * 4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials;
         std::vector<uint4> host(n_vec4);
         WideNode* wn = reinterpret_cast<WideNode*>(host.data());
         for (uint32_t i = 0; i < w->n_nodes; i++) {
@@ -93,13 +94,20 @@ struct DeviceScene {
         for (uint32_t i = 0; i < w->n_prims; i++) {
             const rt_prim& pr = w->prims[i];
             sph[i] = make_float4(pr.c0[0], pr.c0[1], pr.c0[2], pr.radius);
-            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(pr.mat & ~RT_PRIM_MOVING));
+            uint32_t mi = pr.mat & ~RT_PRIM_MOVING;
+            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(mi | (w->materials[mi].type << 30)));
+        }
+        float4* m16 = ext + w->n_prims;
+        for (uint32_t i = 0; i < w->n_materials; i++) {
+            const rt_material& m = w->materials[i];
+            m16[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
         }
         HIP_TRY(blob.upload(host.data(), n_vec4 * sizeof(uint4)));
         packed.blob = blob.as<uint4>();
         packed.blob_vec4 = (uint32_t)n_vec4;
         packed.off_spheres = n_inner * 4;
         packed.off_extra = n_inner * 4 + w->n_prims;
+        packed.off_mats = n_inner * 4 + w->n_prims * 2;
         packed.root_ref = ref_of(w->root);
         for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
         packed.stack_cap = true_stack ? true_stack : 1u;
@@ -210,6 +218,7 @@ struct rt_renderer {
     uint32_t stream_lds_bytes = 0;
     uint32_t stream_blocks_per_cu = 0;
     uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
+    uint32_t tune[3] = {RT_INNER_KEEP, RT_SHADE_MIN, RT_LEAF_MIN};  // scheduling thresholds of the streaming kernel
     size_t shard_floats = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -237,6 +246,12 @@ struct rt_renderer {
         if (want == 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variant 3 needs every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
+        if (const char* env = std::getenv("RT06_TUNE")) {  // "keep,shade,leaf" — scheduling experiments only; results never change
+            unsigned a = 0, b = 0, c = 0;
+            if (std::sscanf(env, "%u,%u,%u", &a, &b, &c) == 3 && a >= 1 && a <= 64 && b >= 1 && b <= 64 && c >= 1 && c <= 64) {
+                tune[0] = a; tune[1] = b; tune[2] = c;
+            }
+        }
         if (variant >= 2) {
             uint64_t budget = 8ull << 30;  // HBM for one pass of per-sample radiance (12 B each)
             if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // tests force multi-pass rendering with this
@@ -279,6 +294,7 @@ struct rt_renderer {
         p.scene = scene.packed;
         p.samples = samples.as<float>();
         p.work_counter = work_counter.as<uint32_t>();
+        p.inner_keep = tune[0]; p.shade_min = tune[1]; p.leaf_min = tune[2];
         uint32_t n_local_pixels = tm.n_local_tiles * RT_TILE * RT_TILE;
         uint32_t grid = n_cus * stream_blocks_per_cu;
         for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp) {
@@ -462,7 +478,7 @@ __global__ void probe_scatter_kernel(uint64_t seed, size_t n, const rt_material*
     scattered[i] = material_scatter(mats[i], in, rec, g, out, att) ? 1 : 0;
     st3(out_rays + 7 * i, out.o); st3(out_rays + 7 * i + 3, out.d); out_rays[7 * i + 6] = out.time;
     st3(atten + 3 * i, att);
-    draws[i] = g.draw;
+    draws[i] = g.blk;
 }
 __global__ void probe_camera_kernel(uint64_t seed, rt_camera cam, size_t n, const float* st, const uint32_t* keys, float* out_rays, uint32_t* draws) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,7 +487,7 @@ __global__ void probe_camera_kernel(uint64_t seed, rt_camera cam, size_t n, cons
     g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
     Ray r = camera_sample_ray(cam, st[2 * i], st[2 * i + 1], g);
     st3(out_rays + 7 * i, r.o); st3(out_rays + 7 * i + 3, r.d); out_rays[7 * i + 6] = r.time;
-    draws[i] = g.draw;
+    draws[i] = g.blk;
 }
 __global__ void probe_radiance_kernel(DeviceWorld w, rt_camera cam, uint32_t width, uint32_t height, uint32_t max_depth,
                                       uint64_t seed, size_t n, const uint32_t* keys, float* out) {
@@ -505,7 +521,11 @@ __global__ void probe_rng_kernel(uint64_t seed, size_t n, const uint32_t* keys, 
     if (i >= n) return;
     Rng g;
     g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
-    for (uint32_t k = 0; k < n_draws; k++) out[i * n_draws + k] = g.next();
+    float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (uint32_t k = 0; k < n_draws; k++) {
+        if ((k & 3u) == 0u) g.block(u[0], u[1], u[2], u[3]);
+        out[i * n_draws + k] = u[k & 3u];
+    }
 }
 
 #define PROBE_GRID(n) dim3((unsigned)(((n) + 127) / 128)), dim3(128)

@@ -36,8 +36,10 @@
 
 #define RT_STREAM_BLOCK 512      // 8 wavefronts share one LDS copy of the scene
 #define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
+// scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
 #define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
-#define RT_SHADE_MIN 16          // run the shade/regenerate phase once this many lanes wait for it
+#define RT_SHADE_MIN 24          // run the shade/regenerate phase once this many lanes wait for it
+#define RT_LEAF_MIN 1            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
 // 64-B wide node: both child boxes + both child references.
 // ref >= 0: wide-node index.  ref < 0: leaf, code = -ref - 1 = prim * 2 + is_moving.
@@ -48,15 +50,17 @@ struct WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
+// LDS image, in 16-B units:  [wide nodes (4 each) | spheres (c0, r) | extra (c1, mat | type << 30) | mats16 (albedo, param)]
 struct PackedSceneRef {
-    const uint4* blob;       // [wide nodes | spheres | extra], 16-B units
+    const uint4* blob;
     uint32_t blob_vec4;      // number of 16-B units to stage into LDS
-    uint32_t off_spheres;    // 16-B units
-    uint32_t off_extra;      // 16-B units
+    uint32_t off_spheres;
+    uint32_t off_extra;
+    uint32_t off_mats;
     int32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
-    const rt_material* mats; // global memory (read once per bounce)
+    const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
 };
 
 struct StreamParams {
@@ -68,12 +72,22 @@ struct StreamParams {
     uint32_t pass_first_s;   // first sample index of this pass
     uint32_t pass_spp;       // samples per pixel in this pass
     uint32_t total;          // n_local_pixels * pass_spp
-    float* samples;          // [n_local_pixels/64][pass_spp][64][3]
+    uint32_t inner_keep, shade_min, leaf_min;
+    float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
     uint32_t* work_counter;
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// pixel origin of the 8x8 tile that local 64-pixel block `blk` covers; false for a padding block
+__device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, uint32_t& x0, uint32_t& y0) {
+    uint32_t gt = blk * tm.world_size + tm.rank;
+    uint32_t ty = gt / tm.tiles_x;
+    x0 = (gt - ty * tm.tiles_x) * RT_TILE;
+    y0 = ty * RT_TILE;
+    return gt < tm.n_tiles;
 }
 
 enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
@@ -96,11 +110,12 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
     const float4* nodes = reinterpret_cast<const float4*>(lds);
     const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
     const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
+    const float4* mats16 = reinterpret_cast<const float4*>(lds + p.scene.off_mats);
     int32_t* stack = reinterpret_cast<int32_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
-    const uint32_t samples_per_block = 64u * p.pass_spp;  // sample indices per 64-pixel block
+    const uint32_t spb = 64u * p.pass_spp;  // sample indices per 64-pixel block
 
     // ---- per-lane path state ------------------------------------------------------------------------
     Ray ray;
@@ -118,8 +133,11 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
     uint32_t state = ST_NEED;
 
-    // ---- wave-uniform work pool ---------------------------------------------------------------------
+    // ---- wave-uniform work pool: [pool_next, pool_end) + the tile origins of its current block(s) -----
     uint32_t pool_next = 0, pool_end = 0;
+    uint32_t pool_blk = 0, pool_rem = 0;      // pool_next == pool_blk * spb + pool_rem
+    uint32_t ax0 = 0, ay0 = 0, bx0 = 0, by0 = 0;
+    bool a_ok = false, b_ok = false;          // origin/validity of block pool_blk (a) and pool_blk + 1 (b)
     bool pool_dry = false;
 
 // BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
@@ -193,31 +211,37 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 }
             }
             bool still = (state == ST_TRAV) && (cur >= 0);
-            if (__popcll(__ballot(still)) < RT_INNER_KEEP) break;
+            if ((uint32_t)__popcll(__ballot(still)) < p.inner_keep) break;
         }
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
-        if ((state == ST_TRAV) && (cur < 0)) {
-            uint32_t code = (uint32_t)(-cur - 1);
-            uint32_t prim = code >> 1;
-            float4 sph = spheres[prim];
-            f3 center = mk3(sph.x, sph.y, sph.z);
-            if (code & 1u) {
-                float4 ex = extra[prim];
-                center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+        {
+            bool at_leaf = (state == ST_TRAV) && (cur < 0);
+            uint64_t m_leaf = __ballot(at_leaf);
+            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot((state == ST_TRAV) && (cur >= 0)) == 0ull)) {
+                if (at_leaf) {
+                    uint32_t code = (uint32_t)(-cur - 1);
+                    uint32_t prim = code >> 1;
+                    float4 sph = spheres[prim];
+                    f3 center = mk3(sph.x, sph.y, sph.z);
+                    if (code & 1u) {
+                        float4 ex = extra[prim];
+                        center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                    }
+                    float t = sphere_closest_intersection(ray, center, sph.w);
+                    if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
+                        rec_t = t;
+                        rec_code = (int32_t)code;
+                    }
+                    RT_POP();
+                }
             }
-            float t = sphere_closest_intersection(ray, center, sph.w);
-            if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
-                rec_t = t;
-                rec_code = (int32_t)code;
-            }
-            RT_POP();
         }
 
         // ================= phase 3: shade finished traces, regenerate finished paths ==================
         uint64_t m_wait = __ballot(state == ST_SHADE || state == ST_NEED);
         uint64_t m_trav = __ballot(state == ST_TRAV);
-        if (__popcll(m_wait) < RT_SHADE_MIN && m_trav != 0ull) continue;
+        if ((uint32_t)__popcll(m_wait) < p.shade_min && m_trav != 0ull) continue;
 
         if (state == ST_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
             if (rec_code < 0) {
@@ -228,28 +252,70 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
             } else if (depth + 1u >= p.max_depth) {
                 RT_EMIT(0.0f, 0.0f, 0.0f);  // the scatter of the last allowed bounce cannot reach the sky: result is 0
             } else {
+                // ---- what every material needs: hit point, outward normal, material record ----
                 uint32_t prim = (uint32_t)rec_code >> 1;
                 float4 sph = spheres[prim];
                 float4 ex = extra[prim];
                 f3 center = mk3(sph.x, sph.y, sph.z);
                 if ((uint32_t)rec_code & 1u) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
-                HitRec rec;
-                rec.distance = rec_t;
-                rec.normal = (ray_at(ray, rec_t) - center) / sph.w;  // SphereHittable.cu:64 / :100
-                rec.prim = (int32_t)prim;
-                rec.mat = __float_as_uint(ex.w);
-                const float4* mp = reinterpret_cast<const float4*>(p.scene.mats + rec.mat);
-                float4 m0 = mp[0], m1 = mp[1];
-                rt_material m;
-                m.albedo[0] = m0.x; m.albedo[1] = m0.y; m.albedo[2] = m0.z; m.param = m0.w;
-                m.albedo2[0] = m1.x; m.albedo2[1] = m1.y; m.albedo2[2] = m1.z; m.type = __float_as_uint(m1.w);
-                Ray scattered;
-                f3 attenuation;
-                if (!material_scatter(m, ray, rec, rng, scattered, attenuation)) {
+                const f3 hit_p = ray_at(ray, rec_t);
+                f3 normal = (hit_p - center) / sph.w;  // SphereHittable.cu:64 / :100
+                const uint32_t mat_bits = __float_as_uint(ex.w);
+                const uint32_t mtype = mat_bits >> 30;
+                const float4 mrec = mats16[mat_bits & 0x3fffffffu];
+                f3 albedo = mk3(mrec.x, mrec.y, mrec.z);
+                const float mparam = mrec.w;
+
+                // ---- Scatter (cu_materials.cuh:52-64 / 77-95 / 115-143 / 27-40), restructured so that the
+                // ---- wave runs ONE Philox per attempt for all materials together; per-lane arithmetic is
+                // ---- material_scatter()'s, expression by expression.
+                const bool is_diel = (mtype == RT_MAT_DIELECTRIC);
+                f3 unit_dir = mk3(0.0f);
+                float ior_ratio = 0.0f, reflect_prob = 0.0f;
+                bool must_reflect = false;
+                if (is_diel) {
+                    bool hit_backface = dot(ray.d, normal) > 0;
+                    if (hit_backface) normal = -normal;
+                    ior_ratio = hit_backface ? mparam : 1 / mparam;
+                    unit_dir = normalize(ray.d);
+                    float cos_theta = fminf(dot(-unit_dir, normal), 1.0f);
+                    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    reflect_prob = reflectance(cos_theta, ior_ratio);
+                    must_reflect = ior_ratio * sin_theta > 1.0f;  // short-circuit: no uniform is drawn
+                }
+                float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
+                if (!must_reflect) rng.block(u0, u1, u2, u3);
+                f3 scatter_dir;
+                bool scattered_ok = true;
+                if (is_diel) {
+                    if (must_reflect || reflect_prob > u0) scatter_dir = reflect(unit_dir, normal);
+                    else scatter_dir = refract(unit_dir, normal, ior_ratio);
+                } else {
+                    f3 v;
+                    bool ok = on_unit3_try(u0, u1, u2, v);
+                    while (!ok) {  // rejection loop of cuRandomOnUnit<3>: a fresh block per attempt
+                        rng.block(u0, u1, u2, u3);
+                        ok = on_unit3_try(u0, u1, u2, v);
+                    }
+                    f3 on_unit = normalize(v);
+                    if (mtype == RT_MAT_METAL) {
+                        scatter_dir = reflect(ray.d, normal) + on_unit * mparam;
+                        scattered_ok = !(dot(scatter_dir, normal) < 0 || near_zero(scatter_dir));
+                    } else {
+                        scatter_dir = normal + on_unit;
+                        scattered_ok = !near_zero(scatter_dir);
+                        if (mtype == RT_MAT_LAMBERTIAN_CHECKER) {
+                            const rt_material& mg = p.scene.mats[mat_bits & 0x3fffffffu];
+                            albedo = checker_value(albedo, mk3(mg.albedo2[0], mg.albedo2[1], mg.albedo2[2]), mparam, hit_p);
+                        }
+                    }
+                }
+                if (!scattered_ok) {
                     RT_EMIT(0.0f, 0.0f, 0.0f);
                 } else {
-                    atten = atten * attenuation;
-                    ray = scattered;
+                    atten = atten * albedo;
+                    ray.o = hit_p;
+                    ray.d = scatter_dir;  // time is inherited
                     ray.o = ray.o + ray.d * 0.001f;  // Renderer.cu:175
                     depth++;
                     RT_BEGIN_TRACE();
@@ -269,21 +335,30 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 if (base >= p.total) { pool_dry = true; break; }
                 pool_next = base;
                 pool_end = min(base + RT_CHUNK, p.total);
+                pool_blk = base / spb;
+                pool_rem = base - pool_blk * spb;
+                a_ok = block_origin(p.tm, pool_blk, ax0, ay0);
+                b_ok = block_origin(p.tm, pool_blk + 1u, bx0, by0);
             }
             uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(m_need));
             uint32_t rank = lane_rank(m_need);
             if (state == ST_NEED && rank < take) {
-                // sample index n -> (64-pixel block, sample, pixel in block): [block][sample][pixel]
-                uint32_t n = pool_next + rank;
-                uint32_t blk = n / samples_per_block;
-                uint32_t rem = n - blk * samples_per_block;
-                uint32_t s_local = rem >> 6;
-                uint32_t L = blk * 64u + (rem & 63u);
-                uint32_t gid;
-                if (local_pixel_to_gid(p.tm, L, gid)) {
-                    out_idx = n;
+                // sample index n -> (64-pixel block, sample, pixel in block): n = (blk * pass_spp + s) * 64 + pix
+                uint32_t rem = pool_rem + rank;
+                bool second = rem >= spb;  // rank < 64 <= spb: at most one block boundary
+                if (second) rem -= spb;
+                uint32_t s_local = rem >> 6, pix = rem & 63u;
+                uint32_t x = (second ? bx0 : ax0) + (pix & 7u);
+                uint32_t y = (second ? by0 : ay0) + (pix >> 3);
+                if ((second ? b_ok : a_ok) && x < p.width && y < p.height) {
+                    uint32_t gid = y * p.width + x;
+                    out_idx = pool_next + rank;
                     rng.init(p.seed, gid, p.pass_first_s + s_local, RT_STREAM_RENDER);
-                    ray = primary_ray(p.cam, p.width, p.height, gid, rng);
+                    float psx, psy, ndcx, ndcy;
+                    pixel_ndc(x, y, p.width, p.height, psx, psy, ndcx, ndcy);
+                    float jx, jy;
+                    rng_in_unit2(rng, jx, jy);  // Renderer.cu:199
+                    ray = camera_sample_ray(p.cam, ndcx + jx * psx, ndcy + jy * psy, rng);
                     atten = mk3(1.0f);
                     depth = 0;
                     if (p.max_depth == 0u) RT_EMIT(0.0f, 0.0f, 0.0f);
@@ -292,6 +367,13 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
             }
             pool_next += take;
+            pool_rem += take;
+            if (pool_rem >= spb) {
+                pool_rem -= spb;
+                pool_blk++;
+                ax0 = bx0; ay0 = by0; a_ok = b_ok;
+                b_ok = block_origin(p.tm, pool_blk + 1u, bx0, by0);
+            }
         }
         if (pool_dry && state == ST_NEED) state = ST_OFF;
         if (__ballot(state != ST_OFF) == 0ull) break;
