@@ -37,9 +37,9 @@
 #define RT_STREAM_BLOCK 512      // 8 wavefronts share one LDS copy of the scene
 #define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
-#define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
-#define RT_SHADE_MIN 24          // run the shade/regenerate phase once this many lanes wait for it
-#define RT_LEAF_MIN 1            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
+#define RT_INNER_KEEP 32         // keep iterating inner-node steps while at least this many lanes want one
+#define RT_SHADE_MIN 52          // run the shade/regenerate phase once this many lanes wait for it
+#define RT_LEAF_MIN 4            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
 // 64-B wide node: both child boxes + both child references.
 // ref >= 0: wide-node index.  ref < 0: leaf, code = -ref - 1 = prim * 2 + is_moving.
