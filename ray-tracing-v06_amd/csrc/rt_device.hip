@@ -108,6 +108,8 @@ struct DeviceScene {
         packed.off_spheres = n_inner * 4;
         packed.off_extra = n_inner * 4 + w->n_prims;
         packed.off_mats = n_inner * 4 + w->n_prims * 2;
+        packed.n_inner = n_inner;
+        packed.n_codes = w->n_prims * 2u;
         packed.root_ref = ref_of(w->root);
         for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
         packed.stack_cap = true_stack ? true_stack : 1u;
@@ -216,6 +218,7 @@ struct rt_renderer {
     uint32_t pass_spp = 0;       // samples per pixel per pass
     uint32_t n_cus = 0;
     uint32_t stream_lds_bytes = 0;
+    uint32_t stream_block = RT_STREAM_BLOCK;
     uint32_t stream_blocks_per_cu = 0;
     uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
     uint32_t tune[3] = {RT_INNER_KEEP, RT_SHADE_MIN, RT_LEAF_MIN};  // scheduling thresholds of the streaming kernel
@@ -236,8 +239,14 @@ struct rt_renderer {
         if (want > 3) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
         bool can_stream = scene.has_packed;
         if (can_stream) {
-            stream_lds_bytes = scene.packed.blob_vec4 * 16u + (RT_STREAM_BLOCK / 64u) * 64u * scene.packed.stack_cap * 4u;
-            if (stream_lds_bytes > lds_per_cu) can_stream = false;
+            stream_block = RT_STREAM_BLOCK;
+            if (const char* env = std::getenv("RT06_BLOCK")) {  // occupancy experiments: 512 / 768 / 1024 threads
+                int v = std::atoi(env);
+                if (v == 512 || v == 768 || v == 1024) stream_block = (uint32_t)v;
+            }
+            stream_lds_bytes = scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u;
+            stream_lds_bytes = (stream_lds_bytes + 15u) & ~15u;
+            if (stream_lds_bytes > lds_per_cu || scene.packed.n_inner >= 0x8000u || scene.packed.n_codes >= 0x8000u) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
         if (want == 0) want = can_stream ? (scene.regular_boxes ? 3u : 2u) : 1u;
@@ -246,6 +255,11 @@ struct rt_renderer {
         if (want == 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variant 3 needs every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
+        if (variant == 2) {
+            stream_block = 768;
+            stream_lds_bytes = (scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u + 15u) & ~15u;
+            stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
+        }
         if (const char* env = std::getenv("RT06_TUNE")) {  // "keep,shade,leaf" — scheduling experiments only; results never change
             unsigned a = 0, b = 0, c = 0;
             if (std::sscanf(env, "%u,%u,%u", &a, &b, &c) == 3 && a >= 1 && a <= 64 && b >= 1 && b <= 64 && c >= 1 && c <= 64) {
@@ -264,12 +278,16 @@ struct rt_renderer {
             if (n_local_pixels * pass_spp >= 0xF0000000ull) return rt_fail(RT_ERR_INVALID, "image too large for one pass");
             HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * 12ull)));
             if (pass_spp < cfg.samples_per_pixel) HIP_TRY(running.alloc((size_t)(n_local_pixels * 12ull)));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel_stream<true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&render_kernel_stream<false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(stream_kernel_ptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
         }
         return RT_OK;
+    }
+
+    const void* stream_kernel_ptr() const {
+        if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, 768>);
+        if (stream_block == 768) return reinterpret_cast<const void*>(&render_kernel_stream<false, 768>);
+        if (stream_block == 1024) return reinterpret_cast<const void*>(&render_kernel_stream<false, 1024>);
+        return reinterpret_cast<const void*>(&render_kernel_stream<false, 512>);
     }
 
     int launch(hipStream_t st, float* out) {
@@ -302,9 +320,8 @@ struct rt_renderer {
             p.pass_spp = std::min(pass_spp, cfg.samples_per_pixel - first);
             p.total = n_local_pixels * p.pass_spp;
             HIP_TRY(hipMemsetAsync(work_counter.p, 0, 4, st));
-            if (variant == 2) render_kernel_stream<true><<<grid, RT_STREAM_BLOCK, stream_lds_bytes, st>>>(p);
-            else render_kernel_stream<false><<<grid, RT_STREAM_BLOCK, stream_lds_bytes, st>>>(p);
-            HIP_TRY(hipGetLastError());
+            void* args[] = {&p};
+            HIP_TRY(hipLaunchKernel(stream_kernel_ptr(), dim3(grid), dim3(stream_block), args, stream_lds_bytes, st));
             uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
             resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
             HIP_TRY(hipGetLastError());

@@ -34,11 +34,11 @@
 #include "rt_internal.hpp"
 #include "rt_render_kernels.hpp"
 
-#define RT_STREAM_BLOCK 512      // 8 wavefronts share one LDS copy of the scene
+#define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
 #define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
-#define RT_INNER_KEEP 32         // keep iterating inner-node steps while at least this many lanes want one
-#define RT_SHADE_MIN 52          // run the shade/regenerate phase once this many lanes wait for it
+#define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
+#define RT_SHADE_MIN 56          // run the shade/regenerate phase once this many lanes wait for it
 #define RT_LEAF_MIN 4            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
 // 64-B wide node: both child boxes + both child references.
@@ -60,6 +60,7 @@ struct PackedSceneRef {
     int32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
+    uint32_t n_inner, n_codes;
     const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
 };
 
@@ -96,22 +97,24 @@ enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
 // EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
 //                min/max (rt_fastdiv.hpp) — identical decisions, proven + exhaustively verified; other
 //                rays take the verbatim path lane by lane.
-template <bool EXACT>
-__global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(StreamParams p) {
+template <bool EXACT, int BLOCK>
+__global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
 
     // ---- stage the scene blob: coalesced 16 B per lane --------------------------------------------
-    for (uint32_t i = tid; i < p.scene.blob_vec4; i += RT_STREAM_BLOCK) lds[i] = p.scene.blob[i];
+    for (uint32_t i = tid; i < p.scene.blob_vec4; i += BLOCK) lds[i] = p.scene.blob[i];
     __syncthreads();
 
     const float4* nodes = reinterpret_cast<const float4*>(lds);
     const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
     const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
     const float4* mats16 = reinterpret_cast<const float4*>(lds + p.scene.off_mats);
-    int32_t* stack = reinterpret_cast<int32_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
+    // per-lane traversal stack, 16-bit entries (an LDS-resident scene has < 2^15 nodes and leaf codes):
+    // inner node i -> i, leaf code c -> 0x8000 | c.  Entry k of this lane is stack[k * 64].
+    uint16_t* stack = reinterpret_cast<uint16_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
@@ -164,7 +167,8 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
             state = ST_SHADE;         \
         } else {                      \
             sp--;                     \
-            cur = stack[sp * 64u];    \
+            uint32_t e_ = stack[sp * 64u];                                        \
+            cur = (e_ & 0x8000u) ? -(int32_t)(e_ & 0x7fffu) - 1 : (int32_t)e_;   \
         }                             \
     } while (0)
 #define RT_EMIT(rx, ry, rz)                                   \
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(RT_STREAM_BLOCK, 4) void render_kernel_stream(Strea
                 // conditions ARE the hit flags.  The near child is popped straight away, so it is kept
                 // in `cur` instead of travelling through the stack.
                 if (hl) {
-                    if (hr) { stack[sp * 64u] = right_idx; sp++; }
+                    if (hr) { stack[sp * 64u] = (uint16_t)(right_idx >= 0 ? (uint32_t)right_idx : (0x8000u | (uint32_t)(-right_idx - 1))); sp++; }
                     cur = left_idx;
                 } else if (hr) {
                     cur = right_idx;
