@@ -170,6 +170,11 @@ int rt_scene_set_world_node_tree(rt_scene* s, int32_t root_ref);
  * stay valid until the scene is modified or destroyed.                        */
 int rt_scene_get_flat(const rt_scene* s, rt_world_flat* out);
 
+/* cuHostRND::next (utilities/cuda_utilities/cuHostRND.h:9-32, cuHostRND.cpp:57-65): the host uniform
+ * stream scene factories draw from.  Uniforms first .. first+n-1 of the library's counter-based host
+ * stream for `seed` (each in (0,1]); stateless, so no generator object is needed.                      */
+int rt_host_uniforms(uint64_t seed, uint32_t first, uint32_t n, float* out);
+
 /* Prefab scenes.  The reference draws its layout from cuRAND's host XORWOW
  * stream (cuHostRND, seed 1984), which cannot be reproduced without cuRAND;
  * these use the library's own counter-based host stream with the reference's

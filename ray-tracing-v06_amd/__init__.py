@@ -4,6 +4,6 @@ Holds only what the per-pixel sample loop needs: csrc/ (HIP kernels for gfx950 +
 include/rt06.h, built into csrc/librt06.so) and the host-side mirror of the reference interface.
 The directory name is not a Python identifier; load it with __graft_entry__.load_package().
 """
-from . import api, capi  # noqa: F401
+from . import api, capi  # noqa: F401  (multigpu imports torch; import it explicitly where needed)
 from .api import (DefocusBlurCamera, MotionBlurCamera, PinholeCamera, Renderer, Scene)  # noqa: F401
 from .capi import build_native, lib  # noqa: F401

@@ -61,7 +61,7 @@ SYMBOLS = [
     "rt_scene_add_moving_sphere", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
     "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list", "rt_scene_add_bvh_node",
     "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
-    "rt_scene_three_spheres", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
+    "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
     "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_download", "rt_renderer_shard_floats",
     "rt_renderer_assemble", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
     "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_aabb_regular",
@@ -130,6 +130,7 @@ def lib():
     L.rt_scene_book1_final.argtypes = [C.c_uint64, P(C.c_void_p)]
     L.rt_scene_book2_moving.argtypes = [C.c_uint64, P(C.c_void_p)]
     L.rt_scene_three_spheres.argtypes = [P(C.c_void_p)]
+    L.rt_host_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, f32p]
     L.rt_renderer_create.argtypes = [P(RenderConfig), P(Camera), P(WorldFlat), P(C.c_void_p)]
     L.rt_renderer_destroy.argtypes = [C.c_void_p]
     L.rt_renderer_destroy.restype = None

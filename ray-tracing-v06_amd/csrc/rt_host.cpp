@@ -380,6 +380,17 @@ extern "C" int rt_scene_get_flat(const rt_scene* s, rt_world_flat* out) {
     return RT_OK;
 }
 
+extern "C" int rt_host_uniforms(uint64_t seed, uint32_t first, uint32_t n, float* out) {
+    if (!out && n) return rt_fail(RT_ERR_INVALID, "rt_host_uniforms: null out");
+    Rng g;
+    g.init(seed, 0u, 0u, RT_STREAM_SCENE);
+    for (uint32_t i = 0; i < n; i++) {
+        g.blk = first + i;  // next() = word 0 of block k
+        out[i] = g.next();
+    }
+    return RT_OK;
+}
+
 // ---- prefab scenes ---------------------------------------------------------------------------
 static void add(rt_scene* s, f3 c0, f3 c1, float r, bool moving, uint32_t type, f3 albedo, float param) {
     float a[3], p0[3], p1[3];
