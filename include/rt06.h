@@ -200,7 +200,8 @@ typedef struct rt_render_config {
     /* tile sharding across the GPUs of one node: this renderer owns the 8x8
      * pixel tiles t with t % world_size == rank (row-major tile order).      */
     uint32_t rank, world_size;
-    uint32_t variant;             /* 0 = default kernel; others select tuning variants (bench A/B) */
+    uint32_t variant;             /* 0 = default; 1 baseline, 2 LDS streaming (verbatim box tests), 3 = 2 + fast exact
+                                     division, 4 = 3 + filtered predicates (experimental).  Same image bits for all >= 2. */
 } rt_render_config;
 
 /* Renderer::MakeRenderer (Renderer.cu:31-67).  Copies the flat world and the
@@ -272,6 +273,10 @@ int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t* keys, uint
  * hit/dist of the 5-instruction-division box test (only meaningful where regular == 1).             */
 int rt_probe_aabb_regular(int device, size_t n, const float* boxes, const float* rays, const float* max_dist,
                           int32_t* out_regular, int32_t* out_hit, float* out_dist);
+/* The filtered box-pair predicates of one inner-node visit (rt_fastdiv.hpp): boxes n*12 (left min,max,
+ * right min,max), rays n*6, max_dist n -> out n*8 int32: [regular, uncertain, hit_left, hit_right, swap,
+ * exact hit_left, exact hit_right, exact left_dist > right_dist].                                       */
+int rt_probe_boxpair_filtered(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out);
 /* Exhaustive self-test: for each of n_den divisor significands starting at first_den (0 .. 2^23-1) and
  * ALL 2^23 numerator significands, compare the 5-instruction quotient with IEEE n/d bit for bit.
  * num_exp / den_exp are the unbiased exponents given to numerator and divisor.  Returns the number of

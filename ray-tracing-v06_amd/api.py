@@ -289,3 +289,11 @@ def selftest_fastdiv(first_den, n_den, num_exp=0, den_exp=0, device=0):
     ex = np.zeros(2, np.uint32)
     check(lib().rt_selftest_fastdiv(device, first_den, n_den, num_exp, den_exp, C.byref(bad), ex))
     return bad.value, ex
+
+
+def probe_boxpair_filtered(boxes, rays, max_dist, device=0):
+    n = len(boxes)
+    out = np.zeros((n, 8), np.int32)
+    check(lib().rt_probe_boxpair_filtered(device, n, np.ascontiguousarray(boxes, np.float32), np.ascontiguousarray(rays, np.float32),
+                                          np.ascontiguousarray(max_dist, np.float32), out))
+    return out

@@ -118,7 +118,8 @@ struct DeviceScene {
         regular_boxes = true;
         for (uint32_t i = 0; i < w->n_nodes && regular_boxes; i++)
             for (int k = 0; k < 3; k++)
-                if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k])) regular_boxes = false;
+                if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k]) || !(w->nodes[i].min[k] <= w->nodes[i].max[k]))
+                    regular_boxes = false;  // the last term: non-inverted boxes (entry plane chosen by the sign of d)
         has_packed = true;
         return RT_OK;
     }
@@ -229,14 +230,15 @@ struct rt_renderer {
 
     // Pick the kernel variant and size the per-pass sample buffer.
     //   0 = default (the fastest validated variant), 1 = baseline wave-per-pixel kernel,
-    //   2 = streaming kernel with verbatim box tests, 3 = streaming kernel with the fast exact division.
+    //   2 = streaming kernel with verbatim box tests, 3 = streaming kernel with the fast exact division,
+    //   4 = 3 + filtered box-pair predicates (experimental).
     int plan() {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, cfg.device));
         n_cus = (uint32_t)prop.multiProcessorCount;
         const uint32_t lds_per_cu = 160u * 1024u;  // MI355X_MICROARCH.md: 160 KiB LDS per CU
         uint32_t want = cfg.variant;
-        if (want > 3) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
+        if (want > 4) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
         bool can_stream = scene.has_packed;
         if (can_stream) {
             stream_block = RT_STREAM_BLOCK;
@@ -252,10 +254,10 @@ struct rt_renderer {
         if (want == 0) want = can_stream ? (scene.regular_boxes ? 3u : 2u) : 1u;
         if (want >= 2 && !can_stream)
             return rt_fail(RT_ERR_INVALID, "kernel variant %u needs an RT_WORLD_BVH world whose LDS image fits in 160 KiB", want);
-        if (want == 3 && !scene.regular_boxes)
-            return rt_fail(RT_ERR_INVALID, "kernel variant 3 needs every box coordinate to be 0 or within [2^-40, 2^40)");
+        if (want >= 3 && !scene.regular_boxes)
+            return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
-        if (variant == 2) {
+        if (variant == 2 || variant == 4) {
             stream_block = 768;
             stream_lds_bytes = (scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u + 15u) & ~15u;
             stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
@@ -284,10 +286,11 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
-        if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, 768>);
-        if (stream_block == 768) return reinterpret_cast<const void*>(&render_kernel_stream<false, 768>);
-        if (stream_block == 1024) return reinterpret_cast<const void*>(&render_kernel_stream<false, 1024>);
-        return reinterpret_cast<const void*>(&render_kernel_stream<false, 512>);
+        if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768>);
+        if (variant == 4) return reinterpret_cast<const void*>(&render_kernel_stream<false, true, 768>);
+        if (stream_block == 512) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 512>);
+        if (stream_block == 1024) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 1024>);
+        return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768>);
     }
 
     int launch(hipStream_t st, float* out) {
@@ -313,6 +316,9 @@ struct rt_renderer {
         p.samples = samples.as<float>();
         p.work_counter = work_counter.as<uint32_t>();
         p.inner_keep = tune[0]; p.shade_min = tune[1]; p.leaf_min = tune[2];
+        const bool want_stats = std::getenv("RT06_STATS") != nullptr;
+        p.stats = want_stats ? reinterpret_cast<unsigned long long*>(work_counter.as<uint32_t>() + 16) : nullptr;
+        if (want_stats) HIP_TRY(hipMemsetAsync(work_counter.as<uint32_t>() + 16, 0, 32, st));
         uint32_t n_local_pixels = tm.n_local_tiles * RT_TILE * RT_TILE;
         uint32_t grid = n_cus * stream_blocks_per_cu;
         for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp) {
@@ -325,6 +331,13 @@ struct rt_renderer {
             uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
             resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
             HIP_TRY(hipGetLastError());
+        }
+        if (want_stats) {
+            unsigned long long h[4] = {0, 0, 0, 0};
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(h, p.stats, 32, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[rt06 stats] inner-node visits %llu, verbatim box tests %llu (%.3g); hit unsure %llu, order unsure %llu\n", h[0], h[1],
+                         h[0] ? (double)h[1] / (double)h[0] : 0.0, h[2], h[3]);
         }
         return RT_OK;
     }
@@ -754,5 +767,43 @@ extern "C" int rt_selftest_fastdiv(int device, uint32_t first_den, uint32_t n_de
                                             cnt.as<unsigned long long>(), ex.as<uint32_t>());
     FINISH();
     DOWN(mismatches, cnt, 8); DOWN(example, ex, 8);
+    return RT_OK;
+}
+
+
+// box_pair_filtered vs the exact decisions, on regular inputs only
+__global__ void probe_boxpair_kernel(size_t n, const float* boxes, const float* rays, const float* maxd, int32_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = ld3(rays + 6 * i); r.d = ld3(rays + 6 * i + 3); r.time = 0.0f;
+    const float* b = boxes + 12 * i;
+    bool reg = ray_is_regular(r);
+    for (int k = 0; k < 12; k++) reg = reg && coord_is_regular(b[k]);
+    for (int k = 0; k < 3; k++) reg = reg && b[k] <= b[3 + k] && b[6 + k] <= b[9 + k];
+    int32_t* o = out + 8 * i;
+    for (int k = 0; k < 8; k++) o[k] = 0;
+    o[0] = reg ? 1 : 0;
+    if (!reg) return;
+    f3 inv_d = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    BoxPairDecision d = box_pair_filtered(ld3(b), ld3(b + 3), ld3(b + 6), ld3(b + 9), r, inv_d, maxd[i]);
+    float dl = RT_MISS_DIST, dr = RT_MISS_DIST;
+    bool hl = aabb_intersects(ld3(b), ld3(b + 3), r, maxd[i], dl);
+    bool hr = aabb_intersects(ld3(b + 6), ld3(b + 9), r, maxd[i], dr);
+    o[1] = d.uncertain; o[2] = d.hit_left; o[3] = d.hit_right; o[4] = d.swap;
+    o[5] = hl; o[6] = hr; o[7] = dl > dr;
+}
+
+extern "C" int rt_probe_boxpair_filtered(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out) {
+    if (!boxes || !rays || !max_dist || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_boxpair_filtered: null argument");
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf b, r, m, o;
+    UP(b, boxes, n * 48); UP(r, rays, n * 24); UP(m, max_dist, n * 4);
+    HIP_TRY(o.alloc(n * 32));
+    probe_boxpair_kernel<<<PROBE_GRID(n)>>>(n, b.as<float>(), r.as<float>(), m.as<float>(), o.as<int32_t>());
+    FINISH();
+    DOWN(out, o, n * 32);
     return RT_OK;
 }

@@ -76,6 +76,7 @@ struct StreamParams {
     uint32_t inner_keep, shade_min, leaf_min;
     float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
     uint32_t* work_counter;
+    unsigned long long* stats;  // optional (RT06_STATS=1, variant 4 only): inner-node visits, verbatim visits, hit-unsure, order-unsure
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
@@ -97,7 +98,10 @@ enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
 // EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
 //                min/max (rt_fastdiv.hpp) — identical decisions, proven + exhaustively verified; other
 //                rays take the verbatim path lane by lane.
-template <bool EXACT, int BLOCK>
+// FILTER = true (variant 4, experimental): decide the two box tests of a visit from one-multiply plane
+//                parameters with a safety margin (box_pair_filtered) and fall back to exact quotients only
+//                for near-ties; sound and bit-identical, but not faster yet because ~1.5 % of visits are ties.
+template <bool EXACT, bool FILTER, int BLOCK>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -142,6 +146,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     uint32_t ax0 = 0, ay0 = 0, bx0 = 0, by0 = 0;
     bool a_ok = false, b_ok = false;          // origin/validity of block pool_blk (a) and pool_blk + 1 (b)
     bool pool_dry = false;
+    uint32_t st_visits = 0, st_verbatim = 0, st_why[2] = {0, 0};  // wave-level statistics (scalar): inner-node visits, of which verbatim
 
 // BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
 #define RT_BEGIN_TRACE()                                                   \
@@ -183,21 +188,41 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         for (;;) {
             bool at_inner = (state == ST_TRAV) && (cur >= 0);
             if (__ballot(at_inner) == 0ull) break;
+            if (FILTER && p.stats != nullptr) st_visits += (uint32_t)__popcll(__ballot(at_inner));
             if (at_inner) {
                 const float4* nd = nodes + (uint32_t)cur * 4u;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 int32_t left_idx = __float_as_int(q3.x), right_idx = __float_as_int(q3.y);
-                float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                bool hl, hr;
+                const f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
+                const f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
+                bool hl, hr, swap_lr;
                 if (EXACT || !regular) {
-                    hl = aabb_intersects(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, rec_t, left_dist);
-                    hr = aabb_intersects(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), ray, rec_t, right_dist);
+                    float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                    hl = aabb_intersects(lmin, lmax, ray, rec_t, left_dist);
+                    hr = aabb_intersects(rmin, rmax, ray, rec_t, right_dist);
+                    swap_lr = left_dist > right_dist;
+                } else if (!FILTER) {
+                    float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                    hl = aabb_intersects_regular(lmin, lmax, ray, inv_d, rec_t, left_dist);
+                    hr = aabb_intersects_regular(rmin, rmax, ray, inv_d, rec_t, right_dist);
+                    swap_lr = left_dist > right_dist;
                 } else {
-                    hl = aabb_intersects_regular(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, inv_d, rec_t, left_dist);
-                    hr = aabb_intersects_regular(mk3(q1.z, q1.w, q2.x), mk3(q2.y, q2.z, q2.w), ray, inv_d, rec_t, right_dist);
+                    BoxPairDecision dec = box_pair_filtered(lmin, lmax, rmin, rmax, ray, inv_d, rec_t);
+                    hl = dec.hit_left; hr = dec.hit_right; swap_lr = dec.swap;
+                    if (p.stats != nullptr) {
+                        st_verbatim = __builtin_amdgcn_readfirstlane(st_verbatim) + (uint32_t)__popcll(__ballot(dec.uncertain));
+                        st_why[0] = __builtin_amdgcn_readfirstlane(st_why[0]) + (uint32_t)__popcll(__ballot((dec.why & 3u) != 0u));
+                        st_why[1] = __builtin_amdgcn_readfirstlane(st_why[1]) + (uint32_t)__popcll(__ballot((dec.why & 4u) != 0u));
+                    }
+                    if (dec.uncertain) {  // a hit comparison too close to call (~1e-6 of visits): redo the visit exactly
+                        float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                        hl = aabb_intersects_regular(lmin, lmax, ray, inv_d, rec_t, left_dist);
+                        hr = aabb_intersects_regular(rmin, rmax, ray, inv_d, rec_t, right_dist);
+                        swap_lr = left_dist > right_dist;
+                    }
                 }
                 // assert that left is closer for next step (BVH.cu:90-93)
-                if (left_dist > right_dist) {
+                if (swap_lr) {
                     int32_t ti = left_idx; left_idx = right_idx; right_idx = ti;
                     bool tb = hl; hl = hr; hr = tb;
                 }
@@ -381,6 +406,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         }
         if (pool_dry && state == ST_NEED) state = ST_OFF;
         if (__ballot(state != ST_OFF) == 0ull) break;
+    }
+    if (FILTER && p.stats != nullptr && lane == 0) {
+        atomicAdd(p.stats + 0, (unsigned long long)st_visits);
+        atomicAdd(p.stats + 1, (unsigned long long)st_verbatim);
+        atomicAdd(p.stats + 2, (unsigned long long)st_why[0]);
+        atomicAdd(p.stats + 3, (unsigned long long)st_why[1]);
     }
 #undef RT_BEGIN_TRACE
 #undef RT_POP

@@ -266,8 +266,8 @@ def _render_cpu(which, W, H, spp, depth=50, seed=1984):
     return img, cnt
 
 
-VARIANTS = [1, 2, 3]   # 1 = baseline wave-per-pixel kernel, 2 = streaming LDS kernel, 3 = streaming + fast exact division
-BIT_EXACT_VARIANTS = {2, 3}  # the streaming path sums samples in the reference's order: image == oracle image
+VARIANTS = [1, 2, 3, 4]   # 1 = baseline wave-per-pixel, 2 = streaming LDS kernel, 3 = 2 + fast exact division, 4 = 3 + filtered predicates
+BIT_EXACT_VARIANTS = {2, 3, 4}  # the streaming path sums samples in the reference's order: image == oracle image
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -476,3 +476,41 @@ def test_box_test_with_fast_division_makes_identical_decisions(p):
     # dist may differ in the sign of a zero only (IEEE min/max vs GLM's (y<x)?y:x)
     assert np.array_equal(dist[m] + np.float32(0.0), edist[m] + np.float32(0.0))
     assert bits_equal(np.abs(dist[m]), np.abs(edist[m]))
+
+
+def test_filtered_box_pair_predicates_are_sound(p):
+    """Whenever box_pair_filtered does not say `uncertain`, its three decisions equal the exact ones —
+    on random pairs and on adversarial near-ties (shared faces, rays through edges and corners, rec_t on the
+    entry distance)."""
+    rng = np.random.default_rng(23)
+    n = 1 << 20
+    lo = ((rng.random((n, 3), dtype=np.float32) * 2 - 1) * 12).astype(np.float32)
+    ext = (rng.random((n, 3), dtype=np.float32) * 3 + 0.01).astype(np.float32)
+    left = np.concatenate([lo, lo + ext], axis=1)
+    # right box: a sibling that shares faces with the left one on some axes
+    shift = np.where(rng.random((n, 3)) < 0.5, 0.0, rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    rlo = (lo + shift * ext).astype(np.float32)
+    rext = np.where(rng.random((n, 3)) < 0.5, ext, (rng.random((n, 3), dtype=np.float32) * 3 + 0.01)).astype(np.float32)
+    right = np.concatenate([rlo, rlo + rext], axis=1)
+    boxes = np.ascontiguousarray(np.concatenate([left, right], axis=1), dtype=np.float32)
+    rays = random_rays(rng, n, with_time=False)
+    # aim a quarter of the rays exactly at a corner / edge point of the left box
+    k = np.arange(0, n // 4)
+    corner = np.where(rng.random((len(k), 3)) < 0.5, left[k, 0:3], left[k, 3:6]).astype(np.float32)
+    rays[k, 3:6] = (corner - rays[k, 0:3]) * (rng.random((len(k), 1), dtype=np.float32) + 0.5)
+    maxd = np.where(rng.random(n) < 0.5, np.float32(3.402823466e38), rng.random(n, dtype=np.float32) * 30).astype(np.float32)
+    # rec_t exactly on the left box's entry distance for some cases
+    hit, dist = p.api.probe_aabb(np.ascontiguousarray(boxes[:, 0:6]), rays, np.full(n, 3.402823466e38, np.float32))
+    kk = np.where(hit[: n // 8] == 1)[0]
+    maxd[kk] = dist[kk]
+    out = p.api.probe_boxpair_filtered(boxes, rays, maxd)
+    reg = out[:, 0] == 1
+    sure = reg & (out[:, 1] == 0)
+    assert reg.mean() > 0.95
+    assert np.array_equal(out[sure, 2], out[sure, 5]), "hit_left differs"
+    assert np.array_equal(out[sure, 3], out[sure, 6]), "hit_right differs"
+    assert np.array_equal(out[sure, 4], out[sure, 7]), "near/far order differs"
+    unc_rate = out[reg, 1].mean()
+    print(f"filtered predicates: uncertain on {unc_rate:.2e} of {reg.sum()} adversarial visits")
+    assert unc_rate < 0.4  # adversarial set (a quarter of the rays aim exactly at a box corner); ~1e-6 in real traversals
+    assert out[sure, 2].mean() > 0.05 and out[sure, 4].mean() > 0.01
