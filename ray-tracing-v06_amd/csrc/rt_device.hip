@@ -76,20 +76,19 @@ struct DeviceScene {
         };
         if (w->n_prims >= (1u << 29)) return RT_OK;  // leaf code would not fit
         if (w->n_materials >= (1u << 30)) return RT_OK;
-        size_t n_vec4 = (size_t)n_inner * 4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials;
-        std::vector<uint4> host(n_vec4);
-        WideNode* wn = reinterpret_cast<WideNode*>(host.data());
+        size_t n_vec4 = (size_t)n_inner * RT_NODE_VEC4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials;
+        std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));
         for (uint32_t i = 0; i < w->n_nodes; i++) {
             if (wide_of[i] < 0) continue;
             const rt_bvh_node& n = w->nodes[i];
             const rt_bvh_node& l = w->nodes[n.left];
             const rt_bvh_node& r = w->nodes[n.right];
-            WideNode& o = wn[wide_of[i]];
+            WideNode& o = *reinterpret_cast<WideNode*>(host.data() + (size_t)wide_of[i] * RT_NODE_VEC4);
             for (int k = 0; k < 3; k++) { o.lmin[k] = l.min[k]; o.lmax[k] = l.max[k]; o.rmin[k] = r.min[k]; o.rmax[k] = r.max[k]; }
             o.lref = ref_of(n.left); o.rref = ref_of(n.right);
             o.pad[0] = o.pad[1] = 0;
         }
-        float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)n_inner * 4);
+        float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)n_inner * RT_NODE_VEC4);
         float4* ext = sph + w->n_prims;
         for (uint32_t i = 0; i < w->n_prims; i++) {
             const rt_prim& pr = w->prims[i];
@@ -105,9 +104,9 @@ struct DeviceScene {
         HIP_TRY(blob.upload(host.data(), n_vec4 * sizeof(uint4)));
         packed.blob = blob.as<uint4>();
         packed.blob_vec4 = (uint32_t)n_vec4;
-        packed.off_spheres = n_inner * 4;
-        packed.off_extra = n_inner * 4 + w->n_prims;
-        packed.off_mats = n_inner * 4 + w->n_prims * 2;
+        packed.off_spheres = n_inner * RT_NODE_VEC4;
+        packed.off_extra = n_inner * RT_NODE_VEC4 + w->n_prims;
+        packed.off_mats = n_inner * RT_NODE_VEC4 + w->n_prims * 2;
         packed.n_inner = n_inner;
         packed.n_codes = w->n_prims * 2u;
         packed.root_ref = ref_of(w->root);

@@ -36,6 +36,7 @@
 
 #define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
 #define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
+#define RT_NODE_VEC4 4u          // LDS stride of a wide node in 16-B units (padding to 5 spreads bank quads but measured no gain)
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
 #define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
 #define RT_SHADE_MIN 56          // run the shade/regenerate phase once this many lanes wait for it
@@ -50,7 +51,7 @@ struct WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
-// LDS image, in 16-B units:  [wide nodes (4 each) | spheres (c0, r) | extra (c1, mat | type << 30) | mats16 (albedo, param)]
+// LDS image, in 16-B units:  [wide nodes (RT_NODE_VEC4 each) | spheres (c0, r) | extra (c1, mat | type << 30) | mats16 (albedo, param)]
 struct PackedSceneRef {
     const uint4* blob;
     uint32_t blob_vec4;      // number of 16-B units to stage into LDS
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             inv_d = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);   \
         }                                                                  \
         float d_root_;                                                     \
-        if (aabb_intersects(root_min, root_max, ray, rec_t, d_root_)) {    \
+        bool hit_root_;                                                    \
+        if (EXACT || !regular) hit_root_ = aabb_intersects(root_min, root_max, ray, rec_t, d_root_);              \
+        else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
+        if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
             sp = 0;                                                        \
             state = ST_TRAV;                                               \
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             if (__ballot(at_inner) == 0ull) break;
             if (FILTER && p.stats != nullptr) st_visits += (uint32_t)__popcll(__ballot(at_inner));
             if (at_inner) {
-                const float4* nd = nodes + (uint32_t)cur * 4u;
+                const float4* nd = nodes + (uint32_t)cur * RT_NODE_VEC4;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 int32_t left_idx = __float_as_int(q3.x), right_idx = __float_as_int(q3.y);
                 const f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         uint64_t m_trav = __ballot(state == ST_TRAV);
         if ((uint32_t)__popcll(m_wait) < p.shade_min && m_trav != 0ull) continue;
 
+        bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
         if (state == ST_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
             if (rec_code < 0) {
                 float t = normalize(ray.d).y * 0.5f + 0.5f;
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     ray.d = scatter_dir;  // time is inherited
                     ray.o = ray.o + ray.d * 0.001f;  // Renderer.cu:175
                     depth++;
-                    RT_BEGIN_TRACE();
+                    start_trace = true;
                 }
             }
         }
@@ -390,8 +395,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     ray = camera_sample_ray(p.cam, ndcx + jx * psx, ndcy + jy * psy, rng);
                     atten = mk3(1.0f);
                     depth = 0;
-                    if (p.max_depth == 0u) RT_EMIT(0.0f, 0.0f, 0.0f);
-                    else RT_BEGIN_TRACE();
+                    if (p.max_depth == 0u) {
+                        RT_EMIT(0.0f, 0.0f, 0.0f);
+                    } else {
+                        start_trace = true;
+                        state = ST_TRAV;  // leaves ST_NEED now (so the loop does not hand it another sample); set for real below
+                    }
                 }
                 // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
             }
@@ -404,6 +413,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 b_ok = block_origin(p.tm, pool_blk + 1u, bx0, by0);
             }
         }
+        if (start_trace) RT_BEGIN_TRACE();
         if (pool_dry && state == ST_NEED) state = ST_OFF;
         if (__ballot(state != ST_OFF) == 0ull) break;
     }

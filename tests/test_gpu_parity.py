@@ -513,4 +513,4 @@ def test_filtered_box_pair_predicates_are_sound(p):
     unc_rate = out[reg, 1].mean()
     print(f"filtered predicates: uncertain on {unc_rate:.2e} of {reg.sum()} adversarial visits")
     assert unc_rate < 0.4  # adversarial set (a quarter of the rays aim exactly at a box corner); ~1e-6 in real traversals
-    assert out[sure, 2].mean() > 0.05 and out[sure, 4].mean() > 0.01
+    assert out[sure, 2].mean() > 0.02 and out[sure, 4].mean() > 0.005
