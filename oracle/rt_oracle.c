@@ -103,16 +103,15 @@ static inline v3 clamp01_sqrt(v3 a) {
 void orc_glm_clamp01_sqrt(const float a[3], float out[3]) { st3(out, clamp01_sqrt(ld3(a))); }
 
 /* ------------------------------------------------------------------ */
-/* RNG — the build's own counter-based generator (Philox4x32-10).      */
-/* Replaces cuRandom (utilities/cuda_utilities/cuRandom.cuh:10-41);    */
-/* keeps its consumption ORDER and its (0,1] range (curand_uniform).   */
-/* Block-granular: block k of a sample is                               */
-/*   philox(counter = (k, sample, pixel, stream), key = seed lo/hi)     */
-/* and every consumer starts on a fresh block:                          */
-/*   next()        word 0 of a new block                                */
-/*   InUnit<2>     tries words (0,1), then (2,3), then a new block      */
-/*   OnUnit<3>     tries words (0,1,2) of a new block per attempt       */
-/* uniform = ((word >> 8) + 1) * 2^-24  (exact in fp32).               */
+/* RNG — the build's own generator, replacing cuRandom                  */
+/* (utilities/cuda_utilities/cuRandom.cuh:10-41): it keeps cuRandom's    */
+/* shape — a sequential stream of uniforms in (0,1] consumed in the      */
+/* reference's order — but the stream belongs to ONE SAMPLE and is       */
+/* seeded counter-based, so no state lives in memory:                    */
+/*   state  = philox4x32-10(counter = (0, sample, pixel, stream),        */
+/*                          key = seed lo/hi)        (128 bits)          */
+/*   next() = xoshiro128++ step on that state (Blackman & Vigna),        */
+/*            u = ((word >> 8) + 1) * 2^-24          (exact in fp32)     */
 /* ------------------------------------------------------------------ */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
     uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
@@ -131,51 +130,54 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 }
 
 typedef struct {
-    uint32_t key[2];
-    uint32_t sample, pixel, stream;
-    uint32_t blk; /* blocks consumed so far */
+    uint32_t s[4];
+    uint32_t draws; /* uniforms consumed so far */
 } rng_t;
 
 static inline void rng_init(rng_t* g, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream) {
-    g->key[0] = (uint32_t)seed; g->key[1] = (uint32_t)(seed >> 32);
-    g->sample = sample; g->pixel = pixel; g->stream = stream; g->blk = 0;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t ctr[4] = {0u, sample, pixel, stream};
+    orc_philox4x32_10(ctr, key, g->s);
+    if ((g->s[0] | g->s[1] | g->s[2] | g->s[3]) == 0u) g->s[0] = 1u; /* xoshiro's one forbidden state */
+    g->draws = 0;
 }
-static inline float u01(uint32_t w) { return (float)((w >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24 */ }
-static inline void rng_block(rng_t* g, float u[4]) {
-    uint32_t ctr[4] = {g->blk, g->sample, g->pixel, g->stream};
-    uint32_t w[4];
-    orc_philox4x32_10(ctr, g->key, w);
-    g->blk++;
-    u[0] = u01(w[0]); u[1] = u01(w[1]); u[2] = u01(w[2]); u[3] = u01(w[3]);
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+static inline uint32_t xoshiro128pp(uint32_t s[4]) {
+    uint32_t result = rotl32(s[0] + s[3], 7) + s[0];
+    uint32_t t = s[1] << 9;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl32(s[3], 11);
+    return result;
 }
 /* cuRandom::next(), cuRandom.cuh:21 (curand_uniform in (0,1]) */
-static inline float rng_next(rng_t* g) { float u[4]; rng_block(g, u); return u[0]; }
+static inline float rng_next(rng_t* g) {
+    uint32_t w = xoshiro128pp(g->s);
+    g->draws++;
+    return (float)((w >> 8) + 1u) * 5.9604644775390625e-08f; /* 2^-24 */
+}
 void orc_rng_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream, uint32_t n, float* out) {
     rng_t g; rng_init(&g, seed, pixel, sample, stream);
-    float u[4];
-    for (uint32_t i = 0; i < n; i++) {
-        if ((i & 3u) == 0u) rng_block(&g, u);
-        out[i] = u[i & 3u];
-    }
+    for (uint32_t i = 0; i < n; i++) out[i] = rng_next(&g);
 }
 /* glm::cuRandomInUnit<2>, utilities/glm_utils.h:84-90 */
 static inline void rng_in_unit2(rng_t* g, float* ox, float* oy) {
     for (;;) {
-        float u[4]; rng_block(g, u);
-        float x = u[0] * 2.0f - 1.0f, y = u[1] * 2.0f - 1.0f;
-        if (length2_2(x, y) < 1.0f) { *ox = x; *oy = y; return; }
-        x = u[2] * 2.0f - 1.0f; y = u[3] * 2.0f - 1.0f;
+        float x = rng_next(g) * 2.0f - 1.0f;
+        float y = rng_next(g) * 2.0f - 1.0f;
         if (length2_2(x, y) < 1.0f) { *ox = x; *oy = y; return; }
     }
 }
 /* glm::cuRandomOnUnit<3>, utilities/glm_utils.h:92-98 */
 static inline v3 rng_on_unit3(rng_t* g) {
     for (;;) {
-        float u[4]; rng_block(g, u);
         v3 v;
-        v.x = u[0] * 2.0f - 1.0f;
-        v.y = u[1] * 2.0f - 1.0f;
-        v.z = u[2] * 2.0f - 1.0f;
+        v.x = rng_next(g) * 2.0f - 1.0f;
+        v.y = rng_next(g) * 2.0f - 1.0f;
+        v.z = rng_next(g) * 2.0f - 1.0f;
         if (!near_zero(v) && length2_3(v) < 1.0f) return normalize(v);
     }
 }
@@ -479,7 +481,7 @@ static inline v3 one_sample(const orc_world* w, const orc_camera* cam, uint32_t 
     ray_t ray = camera_sample_ray(cam, sx, sy, &g);
     v3 rad = sample_world(w, ray, max_depth, &g, cnt, err);
     cnt->samples++;
-    cnt->rng_draws += g.blk;
+    cnt->rng_draws += g.draws;
     return rad;
 }
 
@@ -587,7 +589,7 @@ void orc_scatter_batch(uint64_t seed, size_t n, const orc_material* mats, const 
         ray_t out; out.o = V(0, 0, 0); out.d = V(0, 0, 0); out.time = 0.0f;
         v3 att = V(0, 0, 0);
         out_scattered[i] = material_scatter(&mats[i], &in, &rec, &g, &out, &att);
-        st_ray7(out_rays + 7 * i, &out); st3(out_atten + 3 * i, att); out_draws[i] = g.blk;
+        st_ray7(out_rays + 7 * i, &out); st3(out_atten + 3 * i, att); out_draws[i] = g.draws;
     }
 }
 void orc_camera_batch(uint64_t seed, const orc_camera* cam, size_t n, const float* st, const uint32_t* keys,
@@ -595,7 +597,7 @@ void orc_camera_batch(uint64_t seed, const orc_camera* cam, size_t n, const floa
     for (size_t i = 0; i < n; i++) {
         rng_t g; rng_init(&g, seed, keys[2 * i], keys[2 * i + 1], 0u);
         ray_t r = camera_sample_ray(cam, st[2 * i], st[2 * i + 1], &g);
-        st_ray7(out_rays + 7 * i, &r); out_draws[i] = g.blk;
+        st_ray7(out_rays + 7 * i, &r); out_draws[i] = g.draws;
     }
 }
 int orc_radiance_batch(const orc_world* w, const orc_camera* cam, uint32_t width, uint32_t height, uint32_t max_depth,

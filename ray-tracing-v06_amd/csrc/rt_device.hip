@@ -315,9 +315,6 @@ struct rt_renderer {
         p.samples = samples.as<float>();
         p.work_counter = work_counter.as<uint32_t>();
         p.inner_keep = tune[0]; p.shade_min = tune[1]; p.leaf_min = tune[2];
-        const bool want_stats = std::getenv("RT06_STATS") != nullptr;
-        p.stats = want_stats ? reinterpret_cast<unsigned long long*>(work_counter.as<uint32_t>() + 16) : nullptr;
-        if (want_stats) HIP_TRY(hipMemsetAsync(work_counter.as<uint32_t>() + 16, 0, 32, st));
         uint32_t n_local_pixels = tm.n_local_tiles * RT_TILE * RT_TILE;
         uint32_t grid = n_cus * stream_blocks_per_cu;
         for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp) {
@@ -330,13 +327,6 @@ struct rt_renderer {
             uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
             resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
             HIP_TRY(hipGetLastError());
-        }
-        if (want_stats) {
-            unsigned long long h[4] = {0, 0, 0, 0};
-            HIP_TRY(hipStreamSynchronize(st));
-            HIP_TRY(hipMemcpy(h, p.stats, 32, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "[rt06 stats] inner-node visits %llu, verbatim box tests %llu (%.3g); hit unsure %llu, order unsure %llu\n", h[0], h[1],
-                         h[0] ? (double)h[1] / (double)h[0] : 0.0, h[2], h[3]);
         }
         return RT_OK;
     }
@@ -507,7 +497,7 @@ __global__ void probe_scatter_kernel(uint64_t seed, size_t n, const rt_material*
     scattered[i] = material_scatter(mats[i], in, rec, g, out, att) ? 1 : 0;
     st3(out_rays + 7 * i, out.o); st3(out_rays + 7 * i + 3, out.d); out_rays[7 * i + 6] = out.time;
     st3(atten + 3 * i, att);
-    draws[i] = g.blk;
+    draws[i] = g.draws;
 }
 __global__ void probe_camera_kernel(uint64_t seed, rt_camera cam, size_t n, const float* st, const uint32_t* keys, float* out_rays, uint32_t* draws) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -516,7 +506,7 @@ __global__ void probe_camera_kernel(uint64_t seed, rt_camera cam, size_t n, cons
     g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
     Ray r = camera_sample_ray(cam, st[2 * i], st[2 * i + 1], g);
     st3(out_rays + 7 * i, r.o); st3(out_rays + 7 * i + 3, r.d); out_rays[7 * i + 6] = r.time;
-    draws[i] = g.blk;
+    draws[i] = g.draws;
 }
 __global__ void probe_radiance_kernel(DeviceWorld w, rt_camera cam, uint32_t width, uint32_t height, uint32_t max_depth,
                                       uint64_t seed, size_t n, const uint32_t* keys, float* out) {
@@ -550,11 +540,7 @@ __global__ void probe_rng_kernel(uint64_t seed, size_t n, const uint32_t* keys, 
     if (i >= n) return;
     Rng g;
     g.init(seed, keys[2 * i], keys[2 * i + 1], RT_STREAM_RENDER);
-    float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (uint32_t k = 0; k < n_draws; k++) {
-        if ((k & 3u) == 0u) g.block(u[0], u[1], u[2], u[3]);
-        out[i * n_draws + k] = u[k & 3u];
-    }
+    for (uint32_t k = 0; k < n_draws; k++) out[i * n_draws + k] = g.next();
 }
 
 #define PROBE_GRID(n) dim3((unsigned)(((n) + 127) / 128)), dim3(128)

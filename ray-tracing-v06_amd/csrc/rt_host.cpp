@@ -384,10 +384,8 @@ extern "C" int rt_host_uniforms(uint64_t seed, uint32_t first, uint32_t n, float
     if (!out && n) return rt_fail(RT_ERR_INVALID, "rt_host_uniforms: null out");
     Rng g;
     g.init(seed, 0u, 0u, RT_STREAM_SCENE);
-    for (uint32_t i = 0; i < n; i++) {
-        g.blk = first + i;  // next() = word 0 of block k
-        out[i] = g.next();
-    }
+    for (uint32_t i = 0; i < first; i++) (void)g.next();  // a sequential stream: skip to `first`
+    for (uint32_t i = 0; i < n; i++) out[i] = g.next();
     return RT_OK;
 }
 

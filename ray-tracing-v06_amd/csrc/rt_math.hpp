@@ -80,15 +80,14 @@ struct Ray {
 RT_HD f3 ray_at(const Ray& r, float t) { return r.o + r.d * t; }
 
 // ---------------------------------------------------------------------------------------------
-// Counter-based RNG (Philox4x32-10) replacing cuRandom's per-pixel XORWOW state
-// (utilities/cuda_utilities/cuRandom.cuh:10-41; 48 B/pixel of global-memory state, Renderer.cu:191).
-// Nothing lives in memory: block k of a sample is philox(counter = (k, sample, pixel, stream), key = seed).
-// The generator is BLOCK-granular so that a wavefront always runs Philox convergently (one call site per
-// consumer, never a per-lane "buffer empty?" branch): every consumer starts on a fresh block —
-//   next()      word 0                       (cuRandom::next, cuRandom.cuh:21; range (0,1] like curand_uniform)
-//   InUnit<2>   words (0,1), then (2,3), then a new block   (glm::cuRandomInUnit<2>, utils:84-90)
-//   OnUnit<3>   words (0,1,2) of a new block per attempt    (glm::cuRandomOnUnit<3>, utils:92-98)
-// u = ((word >> 8) + 1) * 2^-24, exact in fp32.  The consumption ORDER is the reference's.
+// RNG replacing cuRandom's per-pixel XORWOW state (utilities/cuda_utilities/cuRandom.cuh:10-41; 48 B/pixel
+// of global-memory state read-modify-written through a reference, Renderer.cu:191).  It keeps cuRandom's
+// shape — a sequential stream of uniforms in (0,1], consumed in the reference's order — but the stream
+// belongs to ONE SAMPLE and is seeded counter-based, so nothing lives in memory:
+//   state  = philox4x32-10(counter = (0, sample, pixel, stream), key = seed)       (4 registers)
+//   next() = one xoshiro128++ step (Blackman & Vigna), u = ((word >> 8) + 1) * 2^-24, exact in fp32
+// One Philox per sample (at regeneration, where every lane runs it together) and ~12 full-rate integer
+// instructions per uniform keep the rejection loops of cuRandomInUnit / cuRandomOnUnit cheap.
 // ---------------------------------------------------------------------------------------------
 #define RT_STREAM_RENDER 0u
 #define RT_STREAM_SCENE 0x5CE9E5u
@@ -110,51 +109,47 @@ RT_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-RT_HD float u01(uint32_t w) { return (float)((w >> 8) + 1u) * 5.9604644775390625e-08f; }
+RT_HD uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
 
 struct Rng {
-    uint32_t k0, k1, sample, pixel, stream;
-    uint32_t blk;  // blocks consumed so far
-    RT_HD void init(uint64_t seed, uint32_t pixel_, uint32_t sample_, uint32_t stream_) {
-        k0 = (uint32_t)seed; k1 = (uint32_t)(seed >> 32);
-        pixel = pixel_; sample = sample_; stream = stream_; blk = 0;
-    }
-    RT_HD void block(float& u0, float& u1, float& u2, float& u3) {
+    uint32_t s0, s1, s2, s3;
+    uint32_t draws;  // uniforms consumed (read only by the probes; dead code in the render kernels)
+    RT_HD void init(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream) {
         uint32_t o[4];
-        philox4x32_10(blk, sample, pixel, stream, k0, k1, o);
-        blk++;
-        u0 = u01(o[0]); u1 = u01(o[1]); u2 = u01(o[2]); u3 = u01(o[3]);
+        philox4x32_10(0u, sample, pixel, stream, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        s0 = o[0]; s1 = o[1]; s2 = o[2]; s3 = o[3];
+        if ((s0 | s1 | s2 | s3) == 0u) s0 = 1u;  // xoshiro's one forbidden state
+        draws = 0;
     }
+    // cuRandom::next(), cuRandom.cuh:21
     RT_HD float next() {
-        float u0, u1, u2, u3;
-        block(u0, u1, u2, u3);
-        return u0;
+        uint32_t result = rotl32(s0 + s3, 7) + s0;
+        uint32_t t = s1 << 9;
+        s2 ^= s0;
+        s3 ^= s1;
+        s1 ^= s2;
+        s0 ^= s3;
+        s2 ^= t;
+        s3 = rotl32(s3, 11);
+        draws++;
+        return (float)((result >> 8) + 1u) * 5.9604644775390625e-08f;
     }
 };
 // glm::cuRandomInUnit<2>, utils:84-90
 RT_HD void rng_in_unit2(Rng& g, float& ox, float& oy) {
     for (;;) {
-        float u0, u1, u2, u3;
-        g.block(u0, u1, u2, u3);
-        float x = u0 * 2.0f - 1.0f, y = u1 * 2.0f - 1.0f;
-        if (length2(x, y) < 1.0f) { ox = x; oy = y; return; }
-        x = u2 * 2.0f - 1.0f; y = u3 * 2.0f - 1.0f;
+        float x = g.next() * 2.0f - 1.0f;
+        float y = g.next() * 2.0f - 1.0f;
         if (length2(x, y) < 1.0f) { ox = x; oy = y; return; }
     }
-}
-// one attempt of glm::cuRandomOnUnit<3> from a block's first three words
-RT_HD bool on_unit3_try(float u0, float u1, float u2, f3& v) {
-    v.x = u0 * 2.0f - 1.0f;
-    v.y = u1 * 2.0f - 1.0f;
-    v.z = u2 * 2.0f - 1.0f;
-    return !near_zero(v) && length2(v) < 1.0f;
 }
 // glm::cuRandomOnUnit<3>, utils:92-98
 RT_HD f3 rng_on_unit3(Rng& g) {
     for (;;) {
-        float u0, u1, u2, u3;
-        g.block(u0, u1, u2, u3);
         f3 v;
-        if (on_unit3_try(u0, u1, u2, v)) return normalize(v);
+        v.x = g.next() * 2.0f - 1.0f;
+        v.y = g.next() * 2.0f - 1.0f;
+        v.z = g.next() * 2.0f - 1.0f;
+        if (!near_zero(v) && length2(v) < 1.0f) return normalize(v);
     }
 }

@@ -77,7 +77,6 @@ struct StreamParams {
     uint32_t inner_keep, shade_min, leaf_min;
     float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
     uint32_t* work_counter;
-    unsigned long long* stats;  // optional (RT06_STATS=1, variant 4 only): inner-node visits, verbatim visits, hit-unsure, order-unsure
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
@@ -147,7 +146,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     uint32_t ax0 = 0, ay0 = 0, bx0 = 0, by0 = 0;
     bool a_ok = false, b_ok = false;          // origin/validity of block pool_blk (a) and pool_blk + 1 (b)
     bool pool_dry = false;
-    uint32_t st_visits = 0, st_verbatim = 0, st_why[2] = {0, 0};  // wave-level statistics (scalar): inner-node visits, of which verbatim
 
 // BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
 #define RT_BEGIN_TRACE()                                                   \
@@ -192,7 +190,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         for (;;) {
             bool at_inner = (state == ST_TRAV) && (cur >= 0);
             if (__ballot(at_inner) == 0ull) break;
-            if (FILTER && p.stats != nullptr) st_visits += (uint32_t)__popcll(__ballot(at_inner));
             if (at_inner) {
                 const float4* nd = nodes + (uint32_t)cur * RT_NODE_VEC4;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
@@ -213,15 +210,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 } else {
                     BoxPairDecision dec = box_pair_filtered(lmin, lmax, rmin, rmax, ray, inv_d, rec_t);
                     hl = dec.hit_left; hr = dec.hit_right; swap_lr = dec.swap;
-                    if (p.stats != nullptr) {
-                        st_verbatim = __builtin_amdgcn_readfirstlane(st_verbatim) + (uint32_t)__popcll(__ballot(dec.uncertain));
-                        st_why[0] = __builtin_amdgcn_readfirstlane(st_why[0]) + (uint32_t)__popcll(__ballot((dec.why & 3u) != 0u));
-                        st_why[1] = __builtin_amdgcn_readfirstlane(st_why[1]) + (uint32_t)__popcll(__ballot((dec.why & 4u) != 0u));
-                    }
-                    if (dec.uncertain) {  // a hit comparison too close to call (~1e-6 of visits): redo the visit exactly
+                    if (dec.uncertain) {
+                        // a comparison too close to call (~1e-6 of visits): redo the visit with exact quotients.
+                        // The node is re-read (volatile) so that the common path need not keep 12 box
+                        // coordinates alive across the filter.
+                        const volatile float4* vnd = reinterpret_cast<const volatile float4*>(nd);
+                        float4 r0, r1, r2;
+                        r0.x = vnd[0].x; r0.y = vnd[0].y; r0.z = vnd[0].z; r0.w = vnd[0].w;
+                        r1.x = vnd[1].x; r1.y = vnd[1].y; r1.z = vnd[1].z; r1.w = vnd[1].w;
+                        r2.x = vnd[2].x; r2.y = vnd[2].y; r2.z = vnd[2].z; r2.w = vnd[2].w;
                         float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                        hl = aabb_intersects_regular(lmin, lmax, ray, inv_d, rec_t, left_dist);
-                        hr = aabb_intersects_regular(rmin, rmax, ray, inv_d, rec_t, right_dist);
+                        hl = aabb_intersects_regular(mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), ray, inv_d, rec_t, left_dist);
+                        hr = aabb_intersects_regular(mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), ray, inv_d, rec_t, right_dist);
                         swap_lr = left_dist > right_dist;
                     }
                 }
@@ -300,8 +300,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 f3 albedo = mk3(mrec.x, mrec.y, mrec.z);
                 const float mparam = mrec.w;
 
-                // ---- Scatter (cu_materials.cuh:52-64 / 77-95 / 115-143 / 27-40), restructured so that the
-                // ---- wave runs ONE Philox per attempt for all materials together; per-lane arithmetic is
+                // ---- Scatter (cu_materials.cuh:52-64 / 77-95 / 115-143 / 27-40); per-lane arithmetic is
                 // ---- material_scatter()'s, expression by expression.
                 const bool is_diel = (mtype == RT_MAT_DIELECTRIC);
                 f3 unit_dir = mk3(0.0f);
@@ -317,21 +316,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     reflect_prob = reflectance(cos_theta, ior_ratio);
                     must_reflect = ior_ratio * sin_theta > 1.0f;  // short-circuit: no uniform is drawn
                 }
-                float u0 = 0.0f, u1 = 0.0f, u2 = 0.0f, u3 = 0.0f;
-                if (!must_reflect) rng.block(u0, u1, u2, u3);
                 f3 scatter_dir;
                 bool scattered_ok = true;
                 if (is_diel) {
-                    if (must_reflect || reflect_prob > u0) scatter_dir = reflect(unit_dir, normal);
+                    if (must_reflect || reflect_prob > rng.next()) scatter_dir = reflect(unit_dir, normal);
                     else scatter_dir = refract(unit_dir, normal, ior_ratio);
                 } else {
-                    f3 v;
-                    bool ok = on_unit3_try(u0, u1, u2, v);
-                    while (!ok) {  // rejection loop of cuRandomOnUnit<3>: a fresh block per attempt
-                        rng.block(u0, u1, u2, u3);
-                        ok = on_unit3_try(u0, u1, u2, v);
-                    }
-                    f3 on_unit = normalize(v);
+                    f3 on_unit = rng_on_unit3(rng);
                     if (mtype == RT_MAT_METAL) {
                         scatter_dir = reflect(ray.d, normal) + on_unit * mparam;
                         scattered_ok = !(dot(scatter_dir, normal) < 0 || near_zero(scatter_dir));
@@ -416,12 +407,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (start_trace) RT_BEGIN_TRACE();
         if (pool_dry && state == ST_NEED) state = ST_OFF;
         if (__ballot(state != ST_OFF) == 0ull) break;
-    }
-    if (FILTER && p.stats != nullptr && lane == 0) {
-        atomicAdd(p.stats + 0, (unsigned long long)st_visits);
-        atomicAdd(p.stats + 1, (unsigned long long)st_verbatim);
-        atomicAdd(p.stats + 2, (unsigned long long)st_why[0]);
-        atomicAdd(p.stats + 3, (unsigned long long)st_why[1]);
     }
 #undef RT_BEGIN_TRACE
 #undef RT_POP
