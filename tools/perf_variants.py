@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Quick variant timing on BASELINE.json configs[1] (dev tool): python tools_perf.py [variants...]
+"""Quick variant timing on BASELINE.json configs[1] (dev tool): python tools/perf_variants.py [variants...]
 env: W H SPP DEPTH SCENE"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 p = G.load_package()
 W, H, spp = int(os.environ.get("W", 1200)), int(os.environ.get("H", 800)), int(os.environ.get("SPP", 500))
