@@ -16,11 +16,11 @@
  * the vector-math vocabulary (GLM 0.9.9.7 vendored under Libraries/include/glm
  * and main/src/utilities/glm_utils.h) compiles with plain g++ from where it
  * lies; oracle/ref_glm_probe.cpp builds it into oracle/_ref/ and generates
- * tests/golden/glm_*.bin, against which every orc_glm_* function here is
+ * tests/golden/glm_*.f32, against which every orc_glm_* function here is
  * checked bit-for-bit.  Everything above that vocabulary (aabb::intersects,
  * sphere test, BVH traversal, Scatter, cameras, sample_world, render_kernel)
  * is restated by hand from the source text: PARITY UNPINNED against an
- * executing reference.  The RNG is the build's own counter-based generator
+ * executing reference.  The RNG is the build's own counter-seeded generator
  * (the reference's cuRAND XORWOW streams are not reproducible offline).
  *
  * Arithmetic contract (shared with the HIP kernels): IEEE fp32, no FMA
@@ -63,7 +63,7 @@ typedef struct {
     uint32_t max_stack;
 } orc_counters;
 
-/* ---- GLM vocabulary (pinned by tests/golden/glm_*.bin) ---- */
+/* ---- GLM vocabulary (pinned by tests/golden/glm_*.f32) ---- */
 float  orc_glm_dot(const float a[3], const float b[3]);
 void   orc_glm_cross(const float a[3], const float b[3], float out[3]);
 void   orc_glm_normalize(const float a[3], float out[3]);
