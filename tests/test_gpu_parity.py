@@ -514,3 +514,87 @@ def test_filtered_box_pair_predicates_are_sound(p):
     print(f"filtered predicates: uncertain on {unc_rate:.2e} of {reg.sum()} adversarial visits")
     assert unc_rate < 0.4  # adversarial set (a quarter of the rays aim exactly at a box corner); ~1e-6 in real traversals
     assert out[sure, 2].mean() > 0.02 and out[sure, 4].mean() > 0.005
+
+
+# ------------------------------------------------------------------------------------------------
+# world shapes and materials beyond the prefab scenes
+# ------------------------------------------------------------------------------------------------
+def _render_both(p, scene, cam, W, H, spp, depth=50, variant=0):
+    w = scene.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w, variant=variant)
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    r.close()
+    ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
+    return img, ref
+
+
+@pytest.mark.parametrize("n_spheres", [1, 2, 3])
+def test_tiny_bvh_worlds_render_bit_exact(p, n_spheres):
+    """A BVH whose root is a leaf (one sphere) or has leaf children only — the streaming kernel's degenerate trees."""
+    s = p.Scene()
+    for i in range(n_spheres):
+        m = [s.Lambertian((0.8, 0.3, 0.3)), s.Metal((0.8, 0.8, 0.8), 0.2), s.Dielectric((1, 1, 1), 1.5)][i]
+        s.MakeSphere((1.2 * i - 1.0, 0.0, -2.0 - 0.3 * i), 0.5, m)
+    s.BuildBVH_TopDown()
+    cam = p.PinholeCamera((0, 0, 0), (0, 0, -1), (0, 1, 0), 70.0, 96 / 64)
+    img, ref = _render_both(p, s, cam, 96, 64, 9)
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    assert (img[..., :3].std() > 0.01)
+
+
+def test_checker_texture_and_moving_spheres_render_bit_exact(p):
+    """LambertianTexture (cu_materials.cuh:16-41, checker_texture cu_Textures.cuh:21-40) on static and moving spheres,
+    through the streaming kernel (second colour read from global memory) and the baseline kernel."""
+    rng = np.random.default_rng(31)
+    s = p.Scene()
+    ground = s.LambertianTexture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9), 0.32)
+    s.MakeSphere((0, -1000, 0), 1000.0, ground)
+    for i in range(24):
+        c = ((rng.random() * 2 - 1) * 4, 0.3, (rng.random() * 2 - 1) * 4)
+        m = s.LambertianTexture(rng.random(3), rng.random(3), 0.1) if i % 2 else s.Metal(rng.random(3), 0.1)
+        if i % 3 == 0:
+            s.MakeMovingSphere(c, (c[0], c[1] + 0.3, c[2]), 0.3, m)
+        else:
+            s.MakeSphere(c, 0.3, m)
+    s.BuildBVH_TopDown()
+    cam = p.MotionBlurCamera((6, 2, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.5, 0.0, 1.0)
+    for variant in (1, 2, 3):
+        img, ref = _render_both(p, s, cam, 120, 80, 11, variant=variant)
+        if variant == 1:
+            assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED
+        else:
+            assert bits_equal(img, ref), mismatch_report(img, ref)
+
+
+def test_hittable_list_and_bvh_node_worlds_render(p):
+    """HittableList and bvh_node worlds run on the baseline kernel (any spp) and agree with the oracle."""
+    s = _node_tree_scene(p, n=40, seed=3)
+    cam = p.PinholeCamera((0, 3, 14), (0, 0, 0), (0, 1, 0), 50.0, 1.5)
+    img, ref = _render_both(p, s, cam, 96, 64, 5)
+    assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED
+    s.MakeHittableList()
+    img2, ref2 = _render_both(p, s, cam, 96, 64, 5)
+    assert np.nanmax(np.abs(img2 - ref2)) <= TOL_MEASURED
+    # the three world kinds over the same spheres give the same closest hits, hence (up to summation order) the same image
+    s.BuildBVH_SAH()
+    img3, ref3 = _render_both(p, s, cam, 96, 64, 5)
+    assert bits_equal(img3, ref3)
+    assert np.nanmax(np.abs(img3 - img2)) <= TOL_MEASURED and np.nanmax(np.abs(img3 - img)) <= TOL_MEASURED
+
+
+def test_irregular_box_coordinates_fall_back_to_the_verbatim_kernel(p):
+    """A box coordinate outside the fast-division class (here 1e-15) must not be rendered by variant 3."""
+    s = p.Scene()
+    m = s.Lambertian((0.5, 0.5, 0.5))
+    s.MakeSphere((0.5, 0.0, -2.0), 0.5, m)
+    s.MakeSphere((2.0, 0.0, -3.0), 0.5, m)
+    s.MakeSphere((2e-15, 0.4, -1.0), 1e-15, m)  # box min.x = 1e-15: not 0 and below 2^-40
+    s.BuildBVH_TopDown()
+    nodes, _, _ = s.arrays()
+    assert np.any((np.abs(nodes["min"]) > 0) & (np.abs(nodes["min"]) < 2.0 ** -40))
+    cam = p.PinholeCamera((0, 0, 0), (0, 0, -1), (0, 1, 0), 70.0, 1.5)
+    with pytest.raises(p.capi.RtError, match="box coordinate"):
+        p.Renderer.MakeRenderer(48, 32, 2, 8, cam, s.getWorldPtr(), variant=3)
+    img, ref = _render_both(p, s, cam, 48, 32, 2, depth=8)  # default resolves to the verbatim streaming kernel
+    assert bits_equal(img, ref), mismatch_report(img, ref)
