@@ -67,14 +67,13 @@ struct DeviceScene {
         uint32_t n_inner = 0;
         for (uint32_t i = 0; i < w->n_nodes; i++)
             if (w->nodes[i].left != -1) wide_of[i] = (int32_t)n_inner++;
-        auto ref_of = [&](int32_t node) -> int32_t {
+        if (w->n_prims * 2u >= RT_REF_LEAF || n_inner >= RT_REF_LEAF) return RT_OK;  // 16-bit references would not fit (such a scene does not fit LDS either)
+        auto ref_of = [&](int32_t node) -> uint32_t {
             const rt_bvh_node& n = w->nodes[node];
-            if (n.left != -1) return wide_of[node];
+            if (n.left != -1) return (uint32_t)wide_of[node];
             uint32_t prim = (uint32_t)n.right;
-            uint32_t code = prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u);
-            return -(int32_t)code - 1;
+            return RT_REF_LEAF | (prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u));
         };
-        if (w->n_prims >= (1u << 29)) return RT_OK;  // leaf code would not fit
         if (w->n_materials >= (1u << 30)) return RT_OK;
         size_t n_vec4 = (size_t)n_inner * RT_NODE_VEC4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials;
         std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));

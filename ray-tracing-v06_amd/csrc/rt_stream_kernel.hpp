@@ -43,10 +43,13 @@
 #define RT_LEAF_MIN 4            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
 // 64-B wide node: both child boxes + both child references.
-// ref >= 0: wide-node index.  ref < 0: leaf, code = -ref - 1 = prim * 2 + is_moving.
+// A reference is 16 bits wide (an LDS-resident scene has < 2^15 inner nodes and leaf codes):
+//   bit 15 clear: wide-node index;  bit 15 set: leaf, code = ref & 0x7fff = prim * 2 + is_moving.
+// The same encoding travels through the per-lane LDS stack as 16-bit entries.
+#define RT_REF_LEAF 0x8000u
 struct WideNode {
     float lmin[3], lmax[3], rmin[3], rmax[3];
-    int32_t lref, rref;
+    uint32_t lref, rref;
     uint32_t pad[2];
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
@@ -58,7 +61,7 @@ struct PackedSceneRef {
     uint32_t off_spheres;
     uint32_t off_extra;
     uint32_t off_mats;
-    int32_t root_ref;
+    uint32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
     uint32_t n_inner, n_codes;
@@ -116,8 +119,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
     const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
     const float4* mats16 = reinterpret_cast<const float4*>(lds + p.scene.off_mats);
-    // per-lane traversal stack, 16-bit entries (an LDS-resident scene has < 2^15 nodes and leaf codes):
-    // inner node i -> i, leaf code c -> 0x8000 | c.  Entry k of this lane is stack[k * 64].
+    // per-lane traversal stack of 16-bit references.  Entry k of this lane is stack[k * 64].
     uint16_t* stack = reinterpret_cast<uint16_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
-    int32_t cur = 0;        // node reference being visited (state ST_TRAV)
+    uint32_t cur = 0;       // node reference being visited (state ST_TRAV)
     uint32_t sp = 0;
     uint32_t depth = 0;
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
@@ -174,8 +176,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             state = ST_SHADE;         \
         } else {                      \
             sp--;                     \
-            uint32_t e_ = stack[sp * 64u];                                        \
-            cur = (e_ & 0x8000u) ? -(int32_t)(e_ & 0x7fffu) - 1 : (int32_t)e_;   \
+            cur = stack[sp * 64u];    \
         }                             \
     } while (0)
 #define RT_EMIT(rx, ry, rz)                                   \
@@ -188,12 +189,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     for (;;) {
         // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
         for (;;) {
-            bool at_inner = (state == ST_TRAV) && (cur >= 0);
+            bool at_inner = (state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u;
             if (__ballot(at_inner) == 0ull) break;
             if (at_inner) {
-                const float4* nd = nodes + (uint32_t)cur * RT_NODE_VEC4;
+                const float4* nd = nodes + cur * RT_NODE_VEC4;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-                int32_t left_idx = __float_as_int(q3.x), right_idx = __float_as_int(q3.y);
+                const uint32_t left_idx = __float_as_uint(q3.x), right_idx = __float_as_uint(q3.y);
                 const f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
                 const f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
                 bool hl, hr, swap_lr;
@@ -225,35 +226,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         swap_lr = left_dist > right_dist;
                     }
                 }
-                // assert that left is closer for next step (BVH.cu:90-93)
-                if (swap_lr) {
-                    int32_t ti = left_idx; left_idx = right_idx; right_idx = ti;
-                    bool tb = hl; hl = hr; hr = tb;
+                // "assert that left is closer for next step" (BVH.cu:90-93), then push far / near iff
+                // dist < rec.distance (BVH.cu:95-96).  A hit box has dist = tmin < rec.distance by aabb.cuh:41 and
+                // a missed one keeps _MISS_DIST, so the push conditions ARE the hit flags.  The near child would
+                // be popped straight away, so it stays in `cur` instead of travelling through the stack.
+                const uint32_t near_idx = swap_lr ? right_idx : left_idx;
+                const uint32_t far_idx = swap_lr ? left_idx : right_idx;
+                const bool hit_near = swap_lr ? hr : hl;
+                const bool hit_far = swap_lr ? hl : hr;
+                if (hit_near && hit_far) {
+                    stack[sp * 64u] = (uint16_t)far_idx;
+                    sp++;
                 }
-                // push far then near iff dist < rec.distance (BVH.cu:95-96); a hit box has
-                // dist = tmin < rec.distance by aabb.cuh:41, a missed one keeps _MISS_DIST, so the push
-                // conditions ARE the hit flags.  The near child is popped straight away, so it is kept
-                // in `cur` instead of travelling through the stack.
-                if (hl) {
-                    if (hr) { stack[sp * 64u] = (uint16_t)(right_idx >= 0 ? (uint32_t)right_idx : (0x8000u | (uint32_t)(-right_idx - 1))); sp++; }
-                    cur = left_idx;
-                } else if (hr) {
-                    cur = right_idx;
-                } else {
-                    RT_POP();
-                }
+                cur = hit_near ? near_idx : far_idx;
+                if (!(hit_near || hit_far)) RT_POP();
             }
-            bool still = (state == ST_TRAV) && (cur >= 0);
+            bool still = (state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u;
             if ((uint32_t)__popcll(__ballot(still)) < p.inner_keep) break;
         }
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
         {
-            bool at_leaf = (state == ST_TRAV) && (cur < 0);
+            bool at_leaf = (state == ST_TRAV) && (cur & RT_REF_LEAF) != 0u;
             uint64_t m_leaf = __ballot(at_leaf);
-            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot((state == ST_TRAV) && (cur >= 0)) == 0ull)) {
+            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot((state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u) == 0ull)) {
                 if (at_leaf) {
-                    uint32_t code = (uint32_t)(-cur - 1);
+                    uint32_t code = cur & 0x7fffu;
                     uint32_t prim = code >> 1;
                     float4 sph = spheres[prim];
                     f3 center = mk3(sph.x, sph.y, sph.z);
