@@ -29,6 +29,10 @@ def gather_shards(shard, world_size, rank, dst=0, group=None):
     Returns the rank-major concatenation of all shards on `dst`, None elsewhere."""
     if world_size == 1:
         return shard
+    if shard.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path (bench.py --backend gloo --same-device on a one-GPU box): gloo gathers host tensors
+        out = gather_shards(shard.cpu(), world_size, rank, dst, group)
+        return out.to(shard.device) if out is not None else None
     if rank == dst:
         gathered = torch.empty(shard.numel() * world_size, dtype=shard.dtype, device=shard.device)
         dist.gather(shard, list(gathered.chunk(world_size)), dst=dst, group=group)
