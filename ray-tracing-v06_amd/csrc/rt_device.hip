@@ -62,30 +62,60 @@ struct DeviceScene {
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
     int pack(const rt_world_flat* w) {
         has_packed = false;
-        if (w->kind != RT_WORLD_BVH) return RT_OK;
-        std::vector<int32_t> wide_of(w->n_nodes, -1);
-        uint32_t n_inner = 0;
-        for (uint32_t i = 0; i < w->n_nodes; i++)
-            if (w->nodes[i].left != -1) wide_of[i] = (int32_t)n_inner++;
-        if (w->n_prims * 2u >= RT_REF_LEAF || n_inner >= RT_REF_LEAF) return RT_OK;  // 16-bit references would not fit (such a scene does not fit LDS either)
-        auto ref_of = [&](int32_t node) -> uint32_t {
-            const rt_bvh_node& n = w->nodes[node];
-            if (n.left != -1) return (uint32_t)wide_of[node];
-            uint32_t prim = (uint32_t)n.right;
+        regular_boxes = false;
+        if (w->n_prims * 2u >= RT_REF_LEAF || w->n_materials >= (1u << 29)) return RT_OK;  // 16-bit references would not fit
+        auto leaf_ref = [&](uint32_t prim) -> uint32_t {
             return RT_REF_LEAF | (prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u));
         };
-        if (w->n_materials >= (1u << 30)) return RT_OK;
+        // wide nodes: BVH -> one per inner node, holding BOTH child boxes; bvh_node tree -> one per node, holding its OWN box
+        std::vector<int32_t> wide_of(w->n_nodes, -1);
+        uint32_t n_inner = 0;
+        if (w->kind == RT_WORLD_BVH) {
+            for (uint32_t i = 0; i < w->n_nodes; i++)
+                if (w->nodes[i].left != -1) wide_of[i] = (int32_t)n_inner++;
+        } else if (w->kind == RT_WORLD_NODE_TREE) {
+            n_inner = w->n_nodes;
+        }
+        if (n_inner >= RT_REF_LEAF) return RT_OK;
         size_t n_vec4 = (size_t)n_inner * RT_NODE_VEC4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials;
         std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));
-        for (uint32_t i = 0; i < w->n_nodes; i++) {
-            if (wide_of[i] < 0) continue;
-            const rt_bvh_node& n = w->nodes[i];
-            const rt_bvh_node& l = w->nodes[n.left];
-            const rt_bvh_node& r = w->nodes[n.right];
-            WideNode& o = *reinterpret_cast<WideNode*>(host.data() + (size_t)wide_of[i] * RT_NODE_VEC4);
-            for (int k = 0; k < 3; k++) { o.lmin[k] = l.min[k]; o.lmax[k] = l.max[k]; o.rmin[k] = r.min[k]; o.rmax[k] = r.max[k]; }
-            o.lref = ref_of(n.left); o.rref = ref_of(n.right);
-            o.pad[0] = o.pad[1] = 0;
+        if (w->kind == RT_WORLD_BVH) {
+            auto ref_of = [&](int32_t node) -> uint32_t {
+                const rt_bvh_node& n = w->nodes[node];
+                return n.left != -1 ? (uint32_t)wide_of[node] : leaf_ref((uint32_t)n.right);
+            };
+            for (uint32_t i = 0; i < w->n_nodes; i++) {
+                if (wide_of[i] < 0) continue;
+                const rt_bvh_node& n = w->nodes[i];
+                const rt_bvh_node& l = w->nodes[n.left];
+                const rt_bvh_node& r = w->nodes[n.right];
+                WideNode& o = *reinterpret_cast<WideNode*>(host.data() + (size_t)wide_of[i] * RT_NODE_VEC4);
+                for (int k = 0; k < 3; k++) { o.lmin[k] = l.min[k]; o.lmax[k] = l.max[k]; o.rmin[k] = r.min[k]; o.rmax[k] = r.max[k]; }
+                o.lref = ref_of(n.left); o.rref = ref_of(n.right);
+                o.pad[0] = o.pad[1] = 0;
+            }
+            packed.root_ref = ref_of(w->root);
+            for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
+            // rt_fastdiv.hpp condition (a): every box coordinate is 0 or 2^-40 <= |b| < 2^40, boxes not inverted
+            regular_boxes = true;
+            for (uint32_t i = 0; i < w->n_nodes && regular_boxes; i++)
+                for (int k = 0; k < 3; k++)
+                    if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k]) || !(w->nodes[i].min[k] <= w->nodes[i].max[k]))
+                        regular_boxes = false;
+        } else if (w->kind == RT_WORLD_NODE_TREE) {
+            auto ref_of = [&](int32_t r) -> uint32_t { return r >= 0 ? (uint32_t)r : leaf_ref((uint32_t)(-r - 1)); };
+            for (uint32_t i = 0; i < w->n_nodes; i++) {
+                const rt_bvh_node& n = w->nodes[i];
+                WideNode& o = *reinterpret_cast<WideNode*>(host.data() + (size_t)i * RT_NODE_VEC4);
+                for (int k = 0; k < 3; k++) { o.lmin[k] = n.min[k]; o.lmax[k] = n.max[k]; o.rmin[k] = 0.0f; o.rmax[k] = 0.0f; }
+                o.lref = ref_of(n.left); o.rref = ref_of(n.right);
+                o.pad[0] = o.pad[1] = 0;
+            }
+            packed.root_ref = ref_of(w->root);
+            for (int k = 0; k < 3; k++) { packed.root_min[k] = w->bounds_min[k]; packed.root_max[k] = w->bounds_max[k]; }
+        } else {  // HittableList: reference = RT_REF_LEAF | primitive index, pre-test against the world bounds
+            packed.root_ref = RT_REF_LEAF | 0u;
+            for (int k = 0; k < 3; k++) { packed.root_min[k] = w->bounds_min[k]; packed.root_max[k] = w->bounds_max[k]; }
         }
         float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)n_inner * RT_NODE_VEC4);
         float4* ext = sph + w->n_prims;
@@ -93,7 +123,8 @@ struct DeviceScene {
             const rt_prim& pr = w->prims[i];
             sph[i] = make_float4(pr.c0[0], pr.c0[1], pr.c0[2], pr.radius);
             uint32_t mi = pr.mat & ~RT_PRIM_MOVING;
-            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(mi | (w->materials[mi].type << 30)));
+            uint32_t moving = (pr.mat & RT_PRIM_MOVING) ? 1u : 0u;
+            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(mi | (moving << 29) | (w->materials[mi].type << 30)));
         }
         float4* m16 = ext + w->n_prims;
         for (uint32_t i = 0; i < w->n_materials; i++) {
@@ -108,16 +139,9 @@ struct DeviceScene {
         packed.off_mats = n_inner * RT_NODE_VEC4 + w->n_prims * 2;
         packed.n_inner = n_inner;
         packed.n_codes = w->n_prims * 2u;
-        packed.root_ref = ref_of(w->root);
-        for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
+        packed.n_prims = w->n_prims;
         packed.stack_cap = true_stack ? true_stack : 1u;
         packed.mats = mats.as<rt_material>();
-        // rt_fastdiv.hpp condition (a): every box coordinate is 0 or 2^-40 <= |b| < 2^40
-        regular_boxes = true;
-        for (uint32_t i = 0; i < w->n_nodes && regular_boxes; i++)
-            for (int k = 0; k < 3; k++)
-                if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k]) || !(w->nodes[i].min[k] <= w->nodes[i].max[k]))
-                    regular_boxes = false;  // the last term: non-inverted boxes (entry plane chosen by the sign of d)
         has_packed = true;
         return RT_OK;
     }
@@ -249,9 +273,11 @@ struct rt_renderer {
             if (stream_lds_bytes > lds_per_cu || scene.packed.n_inner >= 0x8000u || scene.packed.n_codes >= 0x8000u) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
-        if (want == 0) want = can_stream ? (scene.regular_boxes ? 3u : 2u) : 1u;
+        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes) ? 3u : 2u) : 1u;
+        if (want >= 3 && scene.dw.kind != RT_WORLD_BVH)
+            return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need an RT_WORLD_BVH world (a HittableList / bvh_node world runs on variant 2)");
         if (want >= 2 && !can_stream)
-            return rt_fail(RT_ERR_INVALID, "kernel variant %u needs an RT_WORLD_BVH world whose LDS image fits in 160 KiB", want);
+            return rt_fail(RT_ERR_INVALID, "kernel variant %u needs a world whose LDS image fits in 160 KiB", want);
         if (want >= 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
@@ -284,6 +310,8 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
+        if (scene.dw.kind == RT_WORLD_LIST) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST>);
+        if (scene.dw.kind == RT_WORLD_NODE_TREE) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_NODE_TREE>);
         if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768>);
         if (variant == 4) return reinterpret_cast<const void*>(&render_kernel_stream<false, true, 768>);
         if (stream_block == 512) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 512>);

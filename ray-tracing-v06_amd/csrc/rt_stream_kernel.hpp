@@ -54,7 +54,7 @@ struct WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
-// LDS image, in 16-B units:  [wide nodes (RT_NODE_VEC4 each) | spheres (c0, r) | extra (c1, mat | type << 30) | mats16 (albedo, param)]
+// LDS image, in 16-B units:  [wide nodes (RT_NODE_VEC4 each) | spheres (c0, r) | extra (c1, mat | moving << 29 | type << 30) | mats16 (albedo, param)]
 struct PackedSceneRef {
     const uint4* blob;
     uint32_t blob_vec4;      // number of 16-B units to stage into LDS
@@ -64,7 +64,7 @@ struct PackedSceneRef {
     uint32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
-    uint32_t n_inner, n_codes;
+    uint32_t n_inner, n_codes, n_prims;
     const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
 };
 
@@ -104,7 +104,10 @@ enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
 // FILTER = true (variant 4, experimental): decide the two box tests of a visit from one-multiply plane
 //                parameters with a safety margin (box_pair_filtered) and fall back to exact quotients only
 //                for near-ties; sound and bit-identical, but not faster yet because ~1.5 % of visits are ties.
-template <bool EXACT, bool FILTER, int BLOCK>
+// WORLD: RT_WORLD_BVH (default), RT_WORLD_LIST (HittableList: bounds pre-test, then every sphere in order;
+//        a reference is RT_REF_LEAF | primitive index and the "traversal" is the leaf phase alone) or
+//        RT_WORLD_NODE_TREE (bvh_node: a node is tested against ITS OWN box when visited, then left, then right).
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -149,7 +152,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     bool a_ok = false, b_ok = false;          // origin/validity of block pool_blk (a) and pool_blk + 1 (b)
     bool pool_dry = false;
 
-// BVH.cu:59-60: root box first, against rec.distance (= _MISS_DIST for a fresh payload)
+// BVH.cu:59-60 / HittableList.cuh:22: root (world) box first, against rec.distance (= _MISS_DIST for a fresh
+// payload); bvh_node.cuh:20 tests a node's own box when it is visited, so a tree starts at its root unconditionally.
 #define RT_BEGIN_TRACE()                                                   \
     do {                                                                   \
         rec_t = RT_MISS_DIST;                                              \
@@ -160,7 +164,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         }                                                                  \
         float d_root_;                                                     \
         bool hit_root_;                                                    \
-        if (EXACT || !regular) hit_root_ = aabb_intersects(root_min, root_max, ray, rec_t, d_root_);              \
+        if (WORLD == RT_WORLD_NODE_TREE) hit_root_ = true;                 \
+        else if (EXACT || !regular) hit_root_ = aabb_intersects(root_min, root_max, ray, rec_t, d_root_);         \
         else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
@@ -195,6 +200,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 const float4* nd = nodes + cur * RT_NODE_VEC4;
                 float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
                 const uint32_t left_idx = __float_as_uint(q3.x), right_idx = __float_as_uint(q3.y);
+                if (WORLD == RT_WORLD_NODE_TREE) {
+                    // bvh_node::ClosestIntersection (bvh_node.cuh:19-24): own box, then left subtree, then right
+                    float d_own;
+                    if (aabb_intersects(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, rec_t, d_own)) {
+                        stack[sp * 64u] = (uint16_t)right_idx;
+                        sp++;
+                        cur = left_idx;
+                    } else {
+                        RT_POP();
+                    }
+                } else {
                 const f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
                 const f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
                 bool hl, hr, swap_lr;
@@ -240,6 +256,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 }
                 cur = hit_near ? near_idx : far_idx;
                 if (!(hit_near || hit_far)) RT_POP();
+                }
             }
             bool still = (state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u;
             if ((uint32_t)__popcll(__ballot(still)) < p.inner_keep) break;
@@ -251,11 +268,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             uint64_t m_leaf = __ballot(at_leaf);
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot((state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u) == 0ull)) {
                 if (at_leaf) {
-                    uint32_t code = cur & 0x7fffu;
-                    uint32_t prim = code >> 1;
+                    uint32_t code = cur & 0x7fffu;   // BVH / tree: prim * 2 + is_moving;  list: prim
+                    uint32_t prim = (WORLD == RT_WORLD_LIST) ? code : code >> 1;
                     float4 sph = spheres[prim];
                     f3 center = mk3(sph.x, sph.y, sph.z);
-                    if (code & 1u) {
+                    if (WORLD == RT_WORLD_LIST) {
+                        float4 ex = extra[prim];
+                        const uint32_t moving = (__float_as_uint(ex.w) >> 29) & 1u;
+                        code = prim * 2u + moving;
+                        if (moving) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                    } else if (code & 1u) {
                         float4 ex = extra[prim];
                         center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
                     }
@@ -264,7 +286,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         rec_t = t;
                         rec_code = (int32_t)code;
                     }
-                    RT_POP();
+                    if (WORLD == RT_WORLD_LIST) {  // HittableList.cuh:26-30: every object, in order
+                        if (prim + 1u < p.scene.n_prims) cur = RT_REF_LEAF | (prim + 1u);
+                        else state = ST_SHADE;
+                    } else {
+                        RT_POP();
+                    }
                 }
             }
         }
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 f3 normal = (hit_p - center) / sph.w;  // SphereHittable.cu:64 / :100
                 const uint32_t mat_bits = __float_as_uint(ex.w);
                 const uint32_t mtype = mat_bits >> 30;
-                const float4 mrec = mats16[mat_bits & 0x3fffffffu];
+                const float4 mrec = mats16[mat_bits & 0x1fffffffu];
                 f3 albedo = mk3(mrec.x, mrec.y, mrec.z);
                 const float mparam = mrec.w;
 
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         scatter_dir = normal + on_unit;
                         scattered_ok = !near_zero(scatter_dir);
                         if (mtype == RT_MAT_LAMBERTIAN_CHECKER) {
-                            const rt_material& mg = p.scene.mats[mat_bits & 0x3fffffffu];
+                            const rt_material& mg = p.scene.mats[mat_bits & 0x1fffffffu];
                             albedo = checker_value(albedo, mk3(mg.albedo2[0], mg.albedo2[1], mg.albedo2[2]), mparam, hit_p);
                         }
                     }

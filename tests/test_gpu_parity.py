@@ -279,8 +279,8 @@ BIT_EXACT_VARIANTS = {2, 3, 4}  # the streaming path sums samples in the referen
     ("book2_moving", 200, 200, 24),    # configs[2] scene, reduced
 ])
 def test_framebuffer_matches_oracle(p, which, W, H, spp, variant):
-    if which == "three_spheres" and variant >= 2:
-        pytest.skip("the streaming kernel takes RT_WORLD_BVH worlds; a HittableList renders on the baseline kernel")
+    if which == "three_spheres" and variant >= 3:
+        pytest.skip("the fast-division variants take RT_WORLD_BVH worlds; a HittableList renders on variant 2")
     img, _ = _render_gpu(p, which, W, H, spp, variant=variant)
     ref, _ = _render_cpu(which, W, H, spp)
     assert img.shape == ref.shape == (H, W, 4)
@@ -568,19 +568,26 @@ def test_checker_texture_and_moving_spheres_render_bit_exact(p):
 
 
 def test_hittable_list_and_bvh_node_worlds_render(p):
-    """HittableList and bvh_node worlds run on the baseline kernel (any spp) and agree with the oracle."""
+    """HittableList (HittableList.cuh:21-34) and bvh_node (bvh_node.cuh:19-24) worlds: bit-exact on the streaming
+    kernel (their own traversal modes in LDS), summation-order-close on the baseline kernel."""
     s = _node_tree_scene(p, n=40, seed=3)
     cam = p.PinholeCamera((0, 3, 14), (0, 0, 0), (0, 1, 0), 50.0, 1.5)
     img, ref = _render_both(p, s, cam, 96, 64, 5)
-    assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    img_b, _ = _render_both(p, s, cam, 96, 64, 5, variant=1)
+    assert np.nanmax(np.abs(img_b - ref)) <= TOL_MEASURED
+    with pytest.raises(p.capi.RtError, match="RT_WORLD_BVH"):
+        p.Renderer.MakeRenderer(96, 64, 5, 50, cam, s.getWorldPtr(), variant=3)
     s.MakeHittableList()
     img2, ref2 = _render_both(p, s, cam, 96, 64, 5)
-    assert np.nanmax(np.abs(img2 - ref2)) <= TOL_MEASURED
-    # the three world kinds over the same spheres give the same closest hits, hence (up to summation order) the same image
+    assert bits_equal(img2, ref2), mismatch_report(img2, ref2)
+    img2_b, _ = _render_both(p, s, cam, 96, 64, 5, variant=1)
+    assert np.nanmax(np.abs(img2_b - ref2)) <= TOL_MEASURED
+    # the three world kinds over the same spheres give the same closest hits, hence the same image
     s.BuildBVH_SAH()
     img3, ref3 = _render_both(p, s, cam, 96, 64, 5)
     assert bits_equal(img3, ref3)
-    assert np.nanmax(np.abs(img3 - img2)) <= TOL_MEASURED and np.nanmax(np.abs(img3 - img)) <= TOL_MEASURED
+    assert img3.tobytes() == img2.tobytes() == img.tobytes()
 
 
 def test_irregular_box_coordinates_fall_back_to_the_verbatim_kernel(p):
