@@ -348,6 +348,12 @@ struct rt_renderer {
             p.pass_first_s = first;
             p.pass_spp = std::min(pass_spp, cfg.samples_per_pixel - first);
             p.total = n_local_pixels * p.pass_spp;
+            // work-queue granularity: ~32 fetches per wave keep the tail short when a shard is small (multi-GPU)
+            uint32_t n_waves = grid * (stream_block / 64u);
+            uint32_t chunk = p.total / (n_waves * 32u);
+            chunk = std::max(64u, std::min(RT_CHUNK_MAX, chunk & ~63u));
+            if (const char* env = std::getenv("RT06_CHUNK")) { int v = std::atoi(env); if (v >= 64 && v <= 1024) chunk = (uint32_t)v & ~63u; }
+            p.chunk = chunk;
             HIP_TRY(hipMemsetAsync(work_counter.p, 0, 4, st));
             void* args[] = {&p};
             HIP_TRY(hipLaunchKernel(stream_kernel_ptr(), dim3(grid), dim3(stream_block), args, stream_lds_bytes, st));

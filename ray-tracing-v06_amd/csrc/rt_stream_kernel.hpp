@@ -9,7 +9,7 @@
 //    n = (block * pass_spp + s) * 64 + pixel-in-block (a block = the 64 pixels of an 8x8 tile), so the
 //    64 lanes of a wavefront mostly hold one sample each of the 64 pixels of a tile (coherent primary
 //    rays) and n is also the slot of the sample in the HBM sample buffer.  Waves are persistent: each pulls chunks of
-//    RT_CHUNK consecutive sample indices from one global counter and hands them to its lanes with a
+//    `chunk` (<= 1024) consecutive sample indices from one global counter and hands them to its lanes with a
 //    ballot + prefix popcount the moment a lane's path ends (sample regeneration), so path-length
 //    divergence (1..50 bounces) does not idle lanes.
 //  * the lane program is the reference's: primary ray, then trace / scatter per bounce with
@@ -35,7 +35,7 @@
 #include "rt_render_kernels.hpp"
 
 #define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
-#define RT_CHUNK 1024u           // sample indices a wave pulls per atomic
+#define RT_CHUNK_MAX 1024u       // sample indices a wave pulls per atomic (the host shrinks it for small frames / shards)
 #define RT_NODE_VEC4 4u          // LDS stride of a wide node in 16-B units (padding to 5 spreads bank quads but measured no gain)
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
 #define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
@@ -78,6 +78,7 @@ struct StreamParams {
     uint32_t pass_spp;       // samples per pixel in this pass
     uint32_t total;          // n_local_pixels * pass_spp
     uint32_t inner_keep, shade_min, leaf_min;
+    uint32_t chunk;          // sample indices per work-queue fetch
     float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
     uint32_t* work_counter;
 };
@@ -380,11 +381,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             if (pool_next == pool_end) {
                 if (pool_dry) break;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(p.work_counter, RT_CHUNK);
+                if (lane == 0) base = atomicAdd(p.work_counter, p.chunk);
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= p.total) { pool_dry = true; break; }
                 pool_next = base;
-                pool_end = min(base + RT_CHUNK, p.total);
+                pool_end = min(base + p.chunk, p.total);
                 pool_blk = base / spb;
                 pool_rem = base - pool_blk * spb;
                 a_ok = block_origin(p.tm, pool_blk, ax0, ay0);
