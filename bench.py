@@ -80,6 +80,28 @@ def profiled_traffic(kernel_substr):
     return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
+def profiled_valu(kernel_substr):
+    """What actually bounds the kernel (VALU issue), from the same committed PMC summary: wave-instructions per
+    launch, fraction of the VALU issue peak (one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, at the clock
+    GRBM_GUI_ACTIVE / 8 XCDs measured for that launch) and mean fraction of the 64 lanes active per instruction."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_summary.csv")))
+    if not files:
+        return None
+    v = {}
+    for row in csv.DictReader(open(files[-1])):
+        if kernel_substr in row["kernel"]:
+            v[row["counter"]] = float(row["mean_per_dispatch"])
+    need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")
+    if any(k not in v for k in need):
+        return None
+    cycles = v["GRBM_GUI_ACTIVE"] / 8.0
+    return {"wave_instructions_per_launch": v["SQ_INSTS_VALU"],
+            "issue_frac_of_peak": round(v["SQ_INSTS_VALU"] / (1024.0 * cycles * 0.5), 4),
+            "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0), 4)}
+
+
 def count_leg(args):
     """Per-sample box / sphere / hit counts of the algorithmic-bytes model, from a 1-spp oracle pass (N > 1 runs,
     where the timed cpu_baseline leg is skipped)."""
@@ -239,6 +261,7 @@ def main():
                                "samples_per_launch": launch_samples, "kernel_ms": round(kernel_ms, 3),
                                "counts_per_sample": {k: round(v, 3) for k, v in counts.items()},
                                "traffic_source": traffic_src,
+                               "valu": profiled_valu("render_kernel_stream") if default_cfg else None,
                                "note": "algorithmic bytes = BVH node / sphere / material records the traversal touches; they are "
                                        "served from the LDS-resident scene, not HBM, so frac can exceed 1 and measured HBM traffic "
                                        "(the 12-B-per-sample radiance buffer) is ~250x smaller: the kernel is VALU-issue bound "
