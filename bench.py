@@ -150,6 +150,7 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL on this pool; must precede any HIP call
     import torch
     import torch.distributed as dist
 
@@ -165,7 +166,6 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:

@@ -55,3 +55,9 @@ def test_cpp_renderer_matches_c_abi_path_bit_for_bit():
     img = r.DownloadRenderbuffer()
     r.close()
     assert int(m[1], 16) == fnv1a([img.tobytes()])
+
+
+def test_header_is_plain_c_and_the_library_links_from_c():
+    build_app()
+    out = subprocess.check_output([os.path.join(ROOT, "tests", "cpp", "abi_c_check")], text=True)
+    assert "C ABI ok" in out
