@@ -66,11 +66,26 @@ typedef struct rt_prim {
     uint32_t mat;
 } rt_prim;
 
+/* ---- beyond the reference (the reference has no quads, no emission, no background colour:
+ * only the commented `accum_radiance` placeholders of Renderer.cu:142,152,157,163,179).  Semantics follow
+ * "Ray Tracing: The Next Week" (quad(Q,u,v), diffuse_light, camera background) in the reference's conventions.
+ * PARITY UNPINNED: checked GPU against the build's own CPU oracle only. ---- */
+/* quad(Q,u,v,mat): plane point Q, edge vectors u and v; normal/D/w are the cached plane quantities
+ * (n = cross(u,v), normal = unit(n), D = dot(normal,Q), w = n/dot(n,n)), filled by rt_scene_add_quad.  80 B.     */
+typedef struct rt_quad {
+    float    Q[3];      float D;
+    float    u[3];      uint32_t mat;
+    float    v[3];      float pad0;
+    float    normal[3]; float pad1;
+    float    w[3];      float pad2;
+} rt_quad;
+
 enum {
     RT_MAT_LAMBERTIAN = 0,         /* LambertianAbstract  cu_materials.cuh:44-65  param unused          */
     RT_MAT_METAL = 1,              /* MetalAbstract       cu_materials.cuh:68-96  param = fuzz          */
     RT_MAT_DIELECTRIC = 2,         /* DielectricAbstract  cu_materials.cuh:106-144 param = ior          */
-    RT_MAT_LAMBERTIAN_CHECKER = 3  /* LambertianTexture   cu_materials.cuh:16-41  albedo/albedo2 = even/odd colour, param = 1/scale */
+    RT_MAT_LAMBERTIAN_CHECKER = 3, /* LambertianTexture   cu_materials.cuh:16-41  albedo/albedo2 = even/odd colour, param = 1/scale */
+    RT_MAT_DIFFUSE_LIGHT = 4       /* diffuse_light of "The Next Week" (not in the reference): emits albedo, never scatters    */
 };
 typedef struct rt_material {
     float    albedo[3];
@@ -98,6 +113,12 @@ typedef struct rt_world_flat {
     const rt_bvh_node* nodes;
     const rt_prim*     prims;
     const rt_material* materials;
+    /* extension (see rt_quad): a primitive index i >= n_prims means quad i - n_prims                      */
+    const rt_quad*     quads;
+    uint32_t n_quads;
+    uint32_t background;         /* 0: the reference's sky gradient (Renderer.cu:150-151); 1: background_color */
+    float    background_color[3];
+    uint32_t reserved;
 } rt_world_flat;
 
 enum {
@@ -148,6 +169,11 @@ int rt_scene_add_sphere(rt_scene* s, const float center[3], float radius, int32_
 int rt_scene_add_moving_sphere(rt_scene* s, const float c0[3], const float c1[3], float radius,
                                int32_t mat, int32_t* out_prim);
 int rt_scene_prim_bounds(const rt_scene* s, int32_t prim, float out_min[3], float out_max[3]);
+/* quad(Q,u,v,mat) of "The Next Week"; returns the quad index (worlds: BVH builders and HittableList, where the
+ * quads follow the spheres; bvh_node trees take spheres only).                                            */
+int rt_scene_add_quad(rt_scene* s, const float Q[3], const float u[3], const float v[3], int32_t mat, int32_t* out_quad);
+/* camera::background of "The Next Week": mode 0 = the reference's sky gradient, 1 = constant colour       */
+int rt_scene_set_background(rt_scene* s, uint32_t mode, const float color[3]);
 
 /* BVH_Handle::Factory::BuildBVH_TopDown -> _build_bvh_rec1 (BVH.cu:166-210):
  * median split on the longest axis, leaf size 1, post-order numbering, root =
@@ -185,6 +211,9 @@ int rt_host_uniforms(uint64_t seed, uint32_t first, uint32_t n, float* out);
 int rt_scene_book1_final(uint64_t seed, rt_scene** out);
 int rt_scene_book2_moving(uint64_t seed, rt_scene** out);
 int rt_scene_three_spheres(rt_scene** out);
+/* BASELINE.json configs[3]: the Cornell box of "The Next Week" (5 walls, light, two rotated boxes = 18 quads),
+ * black background, median-split BVH.  Not in the reference (no quads / emission there).                  */
+int rt_scene_cornell_box(rt_scene** out);
 
 /* ------------------------------------------------------------------ */
 /* Renderer — main/src/Renderer.h:38-46                                */

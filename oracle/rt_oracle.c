@@ -238,6 +238,34 @@ static inline int prim_closest_intersection(const orc_world* w, int32_t idx, con
     return 1;
 }
 
+/* quad::hit of "Ray Tracing: The Next Week" in the reference's conventions: t >= 0 is accepted (the reference
+ * has no t_min and offsets the origin instead, Renderer.cu:175), `t >= rec.distance` rejects; the stored normal
+ * faces AGAINST the ray (the book's set_face_normal), so a quad is two-sided. */
+static inline int quad_closest_intersection(const orc_world* w, int32_t qi, int32_t unified, const ray_t* ray, rec_t* rec, orc_counters* cnt) {
+    const orc_quad* q = &w->quads[qi];
+    cnt->leaf_tests++;
+    v3 n = ld3(q->normal);
+    float denom = dot(n, ray->d);
+    if (fabsf(denom) < 1e-8f) return 0;
+    float t = (q->D - dot(n, ray->o)) / denom;
+    if (t < 0.0f) return 0;
+    if (t >= rec->distance) return 0;
+    v3 planar = sub(ray_at(ray, t), ld3(q->Q));
+    float alpha = dot(ld3(q->w), cross(planar, ld3(q->v)));
+    float beta = dot(ld3(q->w), cross(ld3(q->u), planar));
+    if (!(alpha >= 0.0f && alpha <= 1.0f && beta >= 0.0f && beta <= 1.0f)) return 0;
+    rec->mat = q->mat;
+    rec->distance = t;
+    rec->prim = unified;
+    rec->normal = (dot(ray->d, n) > 0) ? neg(n) : n;
+    return 1;
+}
+
+static inline int any_prim_closest_intersection(const orc_world* w, int32_t idx, const ray_t* ray, rec_t* rec, orc_counters* cnt) {
+    if ((uint32_t)idx >= w->n_prims) return quad_closest_intersection(w, idx - (int32_t)w->n_prims, idx, ray, rec, cnt);
+    return prim_closest_intersection(w, idx, ray, rec, cnt);
+}
+
 static inline int node_box(const orc_node* n, const ray_t* ray, float maxd, float* dist, orc_counters* cnt) {
     cnt->box_tests++;
     return aabb_intersects(ld3(n->min), ld3(n->max), ray, maxd, dist);
@@ -257,7 +285,7 @@ static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t*
         int32_t idx = stack[--head];
         const orc_node* node = &nodes[idx];
         if (node->left == -1) {
-            hit_any |= prim_closest_intersection(w, node->right, ray, rec, cnt);
+            hit_any |= any_prim_closest_intersection(w, node->right, ray, rec, cnt);
             continue;
         }
         float left_dist = ORC_MISS_DIST, right_dist = ORC_MISS_DIST;
@@ -282,8 +310,8 @@ static int list_closest_intersection(const orc_world* w, const ray_t* ray, rec_t
     cnt->box_tests++;
     if (!aabb_intersects(ld3(w->bounds_min), ld3(w->bounds_max), ray, rec->distance, &d)) return 0;
     int hit_any = 0;
-    for (uint32_t i = 0; i < w->n_prims; i++)
-        if (prim_closest_intersection(w, (int32_t)i, ray, rec, cnt)) hit_any = 1;
+    for (uint32_t i = 0; i < w->n_prims + w->n_quads; i++)
+        if (any_prim_closest_intersection(w, (int32_t)i, ray, rec, cnt)) hit_any = 1;
     return hit_any;
 }
 
@@ -340,6 +368,7 @@ static inline v3 checker_value(const orc_material* m, v3 pos) {
 static int material_scatter(const orc_material* m, const ray_t* in_ray, const rec_t* rec, rng_t* g,
                             ray_t* out, v3* attenuation) {
     v3 normal = rec->normal;
+    if (m->type == 4) return 0; /* diffuse_light of "The Next Week": emits (material_emitted), never scatters */
     switch (m->type) {
     case 0:
     case 3: {
@@ -444,24 +473,33 @@ static inline ray_t camera_sample_ray(const orc_camera* c, float s, float t, rng
 /* ------------------------------------------------------------------ */
 /* sample_world, main/src/Renderer.cu:139-181                          */
 /* ------------------------------------------------------------------ */
+/* The emission / background hooks are the reference's own commented placeholders (Renderer.cu:142,152,157,163,179:
+ * `accum_radiance`); with no emissive material and background 0 this is exactly the live sample_world. */
 static v3 sample_world(const orc_world* w, ray_t cur_ray, uint32_t max_depth, rng_t* g, orc_counters* cnt, int* err) {
     v3 accum_attenuation = V(1.0f, 1.0f, 1.0f);
+    v3 accum_radiance = V(0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < max_depth; i++) {
         rec_t rec; rec.distance = ORC_MISS_DIST; rec.prim = -1; rec.mat = 0; rec.normal = V(0, 0, 0);
         if (!world_closest_intersection(w, &cur_ray, &rec, cnt, err)) {
-            float t = normalize(cur_ray.d).y * 0.5f + 0.5f;
-            v3 sky = lerp3(V(0.1f, 0.2f, 0.4f), V(0.9f, 0.9f, 0.99f), t);
-            return mul(accum_attenuation, sky);
+            v3 sky;
+            if (w->background == 1) sky = ld3(w->background_color);
+            else {
+                float t = normalize(cur_ray.d).y * 0.5f + 0.5f;
+                sky = lerp3(V(0.1f, 0.2f, 0.4f), V(0.9f, 0.9f, 0.99f), t);
+            }
+            return add(mul(accum_attenuation, sky), accum_radiance);
         }
         cnt->shaded_hits++;
+        const orc_material* m = &w->materials[rec.mat];
+        if (m->type == 4) accum_radiance = add(accum_radiance, mul(accum_attenuation, ld3(m->albedo)));
         ray_t scattered; v3 attenuation;
-        if (!material_scatter(&w->materials[rec.mat], &cur_ray, &rec, g, &scattered, &attenuation))
-            return V(0.0f, 0.0f, 0.0f);
+        if (!material_scatter(m, &cur_ray, &rec, g, &scattered, &attenuation))
+            return accum_radiance;
         accum_attenuation = mul(accum_attenuation, attenuation);
         cur_ray = scattered;
         cur_ray.o = add(cur_ray.o, muls(cur_ray.d, 0.001f));
     }
-    return V(0.0f, 0.0f, 0.0f);
+    return accum_radiance;
 }
 
 /* one sample of render_kernel's loop body, Renderer.cu:198-204.  The RNG is
@@ -649,6 +687,8 @@ void orc_sphere_index(const orc_camera* cam, uint32_t width, uint32_t height, si
 /* ------------------------------------------------------------------ */
 struct orc_scene {
     orc_prim* prims; size_t n_prims;
+    orc_quad* quads; size_t n_quads;
+    uint32_t background; float background_color[3];
     orc_material* mats; size_t n_mats;
     orc_node* nodes; size_t n_nodes, cap_nodes;
     orc_world world;
@@ -683,7 +723,28 @@ static float box_surface_area(box_t b) {
 static inline v3 box_centroid(box_t b) { return muls(add(b.mx, b.mn), 0.5f); } /* aabb.cuh:66-68 */
 static inline float v3_axis(v3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
 
-typedef struct { box_t b; orc_prim p; } item_t;
+/* quad cached quantities and bounds, "The Next Week" quad(Q,u,v): n = cross(u,v), normal = unit(n), D = dot(normal,Q),
+ * w = n / dot(n,n); bbox = box(Q, Q+u+v) U box(Q+u, Q+v), every axis padded to at least 0.0001 */
+static void quad_finalize(orc_quad* q) {
+    v3 n = cross(ld3(q->u), ld3(q->v));
+    v3 normal = normalize(n);
+    st3(q->normal, normal);
+    q->D = dot(normal, ld3(q->Q));
+    st3(q->w, divs(n, dot(n, n)));
+    q->pad0 = q->pad1 = q->pad2 = 0.0f;
+}
+static box_t box_of_points(v3 a, v3 b) { box_t r = {vmin(a, b), vmax(a, b)}; return r; }
+static box_t quad_bounds(const orc_quad* q) {
+    v3 Q = ld3(q->Q), u = ld3(q->u), v = ld3(q->v);
+    box_t b = box_union(box_of_points(Q, add(add(Q, u), v)), box_of_points(add(Q, u), add(Q, v)));
+    const float delta = 0.0001f;
+    if (b.mx.x - b.mn.x < delta) { b.mn.x -= delta / 2; b.mx.x += delta / 2; }
+    if (b.mx.y - b.mn.y < delta) { b.mn.y -= delta / 2; b.mx.y += delta / 2; }
+    if (b.mx.z - b.mn.z < delta) { b.mn.z -= delta / 2; b.mx.z += delta / 2; }
+    return b;
+}
+
+typedef struct { box_t b; int is_quad; orc_prim p; orc_quad q; } item_t;
 typedef struct {
     item_t* arr; item_t* tmp;
     orc_scene* s;
@@ -822,38 +883,60 @@ static uint32_t tree_leaf_depth(const orc_node* nodes, int32_t idx) {
 }
 
 static void finish_scene(orc_scene* s, int builder) {
-    size_t n = s->n_prims;
+    size_t ns = s->n_prims, nq = s->n_quads, n = ns + nq;
     orc_world* w = &s->world;
     memset(w, 0, sizeof(*w));
     box_t wb = box_empty();
-    for (size_t i = 0; i < n; i++) wb = box_union(wb, prim_bounds(&s->prims[i]));
+    for (size_t i = 0; i < ns; i++) wb = box_union(wb, prim_bounds(&s->prims[i]));
+    for (size_t i = 0; i < nq; i++) wb = box_union(wb, quad_bounds(&s->quads[i]));
     if (builder == 3) {
         w->kind = 1; w->root = 0;
     } else {
         builder_t B; B.s = s;
         B.arr = (item_t*)malloc(n * sizeof(item_t)); B.tmp = (item_t*)malloc(n * sizeof(item_t));
-        for (size_t i = 0; i < n; i++) { B.arr[i].p = s->prims[i]; B.arr[i].b = prim_bounds(&s->prims[i]); }
+        for (size_t i = 0; i < ns; i++) { B.arr[i].is_quad = 0; B.arr[i].p = s->prims[i]; B.arr[i].b = prim_bounds(&s->prims[i]); }
+        for (size_t i = 0; i < nq; i++) { B.arr[ns + i].is_quad = 1; B.arr[ns + i].q = s->quads[i]; B.arr[ns + i].b = quad_bounds(&s->quads[i]); }
         int32_t root;
         if (builder == 0) root = build_rec1(&B, 0, (int)n);
         else if (builder == 1) root = build_rec2(&B, 0, (int)n);
         else root = build_bottom_up(&B, (int)n);
-        for (size_t i = 0; i < n; i++) s->prims[i] = B.arr[i].p; /* hittables = sorted order, BVH.cu:174-177 */
-        free(B.arr); free(B.tmp);
+        /* hittables = sorted order (BVH.cu:174-177), kept per kind: spheres first, then quads; a leaf's index is remapped */
+        int32_t* unified = (int32_t*)malloc(n * sizeof(int32_t));
+        size_t si = 0, qi = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (B.arr[i].is_quad) { s->quads[qi] = B.arr[i].q; unified[i] = (int32_t)(ns + qi); qi++; }
+            else { s->prims[si] = B.arr[i].p; unified[i] = (int32_t)si; si++; }
+        }
+        for (size_t i = 0; i < s->n_nodes; i++)
+            if (s->nodes[i].left == -1) s->nodes[i].right = unified[s->nodes[i].right];
+        free(unified); free(B.arr); free(B.tmp);
         w->kind = 0; w->root = root;
         w->max_stack = tree_leaf_depth(s->nodes, root) + 1;
         wb.mn = ld3(s->nodes[root].min); wb.mx = ld3(s->nodes[root].max);
     }
-    w->n_nodes = (uint32_t)s->n_nodes; w->n_prims = (uint32_t)n; w->n_materials = (uint32_t)s->n_mats;
+    w->n_nodes = (uint32_t)s->n_nodes; w->n_prims = (uint32_t)ns; w->n_materials = (uint32_t)s->n_mats;
     st3(w->bounds_min, wb.mn); st3(w->bounds_max, wb.mx);
     w->nodes = s->nodes; w->prims = s->prims; w->materials = s->mats;
+    w->quads = s->quads; w->n_quads = (uint32_t)nq;
+    w->background = s->background; st3(w->background_color, ld3(s->background_color));
 }
 
-orc_scene* orc_scene_from_arrays(size_t n_prims, const orc_prim* prims, size_t n_mats, const orc_material* mats, int builder) {
+orc_scene* orc_scene_from_arrays_ext(size_t n_prims, const orc_prim* prims, size_t n_quads, const orc_quad* quads, size_t n_mats,
+                                     const orc_material* mats, int builder, uint32_t background, const float background_color[3]) {
     orc_scene* s = (orc_scene*)calloc(1, sizeof(orc_scene));
-    s->prims = (orc_prim*)malloc(n_prims * sizeof(orc_prim)); memcpy(s->prims, prims, n_prims * sizeof(orc_prim)); s->n_prims = n_prims;
+    s->prims = (orc_prim*)malloc((n_prims + 1) * sizeof(orc_prim)); if (n_prims) memcpy(s->prims, prims, n_prims * sizeof(orc_prim));
+    s->n_prims = n_prims;
+    s->quads = (orc_quad*)malloc((n_quads + 1) * sizeof(orc_quad)); if (n_quads) memcpy(s->quads, quads, n_quads * sizeof(orc_quad));
+    s->n_quads = n_quads;
+    for (size_t i = 0; i < n_quads; i++) quad_finalize(&s->quads[i]);
     s->mats = (orc_material*)malloc(n_mats * sizeof(orc_material)); memcpy(s->mats, mats, n_mats * sizeof(orc_material)); s->n_mats = n_mats;
+    s->background = background;
+    if (background_color) st3(s->background_color, ld3(background_color));
     finish_scene(s, builder);
     return s;
+}
+orc_scene* orc_scene_from_arrays(size_t n_prims, const orc_prim* prims, size_t n_mats, const orc_material* mats, int builder) {
+    return orc_scene_from_arrays_ext(n_prims, prims, 0, NULL, n_mats, mats, builder, 0, NULL);
 }
 
 static void scene_add(orc_prim* prims, orc_material* mats, size_t* n, v3 c0, v3 c1, float r, int moving,
@@ -919,8 +1002,43 @@ orc_scene* orc_scene_three_spheres(void) {
     scene_add(prims, mats, &n, V(1, 0, -1), V(1, 0, -1), 0.5f, 0, 1, V(0.8f, 0.6f, 0.2f), 1.0f);
     return orc_scene_from_arrays(n, prims, n, mats, 3);
 }
+/* Cornell box of "Ray Tracing: The Next Week" (BASELINE.json configs[3]); the two boxes are built as 6 quads each and
+ * rotated about y / translated on the host (the book wraps them in rotate_y / translate instances instead). */
+static void cornell_quad(orc_quad* quads, size_t* n, v3 Q, v3 u, v3 v, uint32_t mat) {
+    orc_quad* q = &quads[(*n)++];
+    memset(q, 0, sizeof(*q));
+    st3(q->Q, Q); st3(q->u, u); st3(q->v, v); q->mat = mat;
+}
+static v3 rot_y(v3 p, float c, float s) { return V(c * p.x + s * p.z, p.y, -s * p.x + c * p.z); }
+static void cornell_box(orc_quad* quads, size_t* n, v3 a, v3 b, float degrees, v3 offset, uint32_t mat) {
+    v3 mn = vmin(a, b), mx = vmax(a, b);
+    v3 dx = V(mx.x - mn.x, 0, 0), dy = V(0, mx.y - mn.y, 0), dz = V(0, 0, mx.z - mn.z);
+    float rad = radians(degrees), c = cosf(rad), sn = sinf(rad);
+    v3 Qs[6] = {V(mn.x, mn.y, mx.z), V(mx.x, mn.y, mx.z), V(mx.x, mn.y, mn.z), V(mn.x, mn.y, mn.z), V(mn.x, mx.y, mx.z), V(mn.x, mn.y, mn.z)};
+    v3 us[6] = {dx, neg(dz), neg(dx), dz, dx, dx};
+    v3 vs[6] = {dy, dy, dy, dy, neg(dz), dz};
+    for (int k = 0; k < 6; k++) cornell_quad(quads, n, add(rot_y(Qs[k], c, sn), offset), rot_y(us[k], c, sn), rot_y(vs[k], c, sn), mat);
+}
+orc_scene* orc_scene_cornell_box(void) {
+    orc_material mats[4]; memset(mats, 0, sizeof(mats));
+    st3(mats[0].albedo, V(0.65f, 0.05f, 0.05f)); mats[0].type = 0;  /* red */
+    st3(mats[1].albedo, V(0.73f, 0.73f, 0.73f)); mats[1].type = 0;  /* white */
+    st3(mats[2].albedo, V(0.12f, 0.45f, 0.15f)); mats[2].type = 0;  /* green */
+    st3(mats[3].albedo, V(15.0f, 15.0f, 15.0f)); mats[3].type = 4;  /* light */
+    orc_quad quads[18]; size_t n = 0;
+    cornell_quad(quads, &n, V(555, 0, 0), V(0, 555, 0), V(0, 0, 555), 2);
+    cornell_quad(quads, &n, V(0, 0, 0), V(0, 555, 0), V(0, 0, 555), 0);
+    cornell_quad(quads, &n, V(343, 554, 332), V(-130, 0, 0), V(0, 0, -105), 3);
+    cornell_quad(quads, &n, V(0, 0, 0), V(555, 0, 0), V(0, 0, 555), 1);
+    cornell_quad(quads, &n, V(555, 555, 555), V(-555, 0, 0), V(0, 0, -555), 1);
+    cornell_quad(quads, &n, V(0, 0, 555), V(555, 0, 0), V(0, 555, 0), 1);
+    cornell_box(quads, &n, V(0, 0, 0), V(165, 330, 165), 15.0f, V(265, 0, 295), 1);
+    cornell_box(quads, &n, V(0, 0, 0), V(165, 165, 165), -18.0f, V(130, 0, 65), 1);
+    float black[3] = {0, 0, 0};
+    return orc_scene_from_arrays_ext(0, NULL, n, quads, 4, mats, 0, 1, black);
+}
 void orc_scene_world(const orc_scene* s, orc_world* out) { *out = s->world; }
 void orc_scene_free(orc_scene* s) {
     if (!s) return;
-    free(s->prims); free(s->mats); free(s->nodes); free(s);
+    free(s->prims); free(s->quads); free(s->mats); free(s->nodes); free(s);
 }

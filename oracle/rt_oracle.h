@@ -45,10 +45,18 @@ typedef struct { float x, y, z; } orc_v3;
 typedef struct { float min[3]; float max[3]; int32_t left; int32_t right; } orc_node;
 typedef struct { float c0[3]; float radius; float c1[3]; uint32_t mat; } orc_prim;
 typedef struct { float albedo[3]; float param; float albedo2[3]; uint32_t type; } orc_material;
+/* quad(Q,u,v) of "Ray Tracing: The Next Week" (absent from the reference: SURVEY.md §8f rank 1); normal, D, w are
+ * the cached plane quantities of that book's quad class */
+typedef struct { float Q[3]; float D; float u[3]; uint32_t mat; float v[3]; float pad0; float normal[3]; float pad1; float w[3]; float pad2; } orc_quad;
 typedef struct {
     uint32_t kind; int32_t root; uint32_t n_nodes, n_prims, n_materials, max_stack;
     float bounds_min[3], bounds_max[3];
     const orc_node* nodes; const orc_prim* prims; const orc_material* materials;
+    /* extension beyond the reference (quads, emission, constant background): primitive index i >= n_prims is quad i - n_prims */
+    const orc_quad* quads; uint32_t n_quads;
+    uint32_t background;        /* 0: the reference's sky gradient (Renderer.cu:150-151); 1: constant background_color */
+    float background_color[3];
+    uint32_t reserved;
 } orc_world;
 typedef struct {
     uint32_t type; float o[3], u[3], v[3], w[3];
@@ -131,6 +139,12 @@ orc_scene* orc_scene_three_spheres(void);
  * 2 = bottom-up, 3 = HittableList                                              */
 orc_scene* orc_scene_from_arrays(size_t n_prims, const orc_prim* prims, size_t n_mats,
                                  const orc_material* mats, int builder);
+/* same with quads (Q,u,v,mat given; cached plane quantities are recomputed) and a background */
+orc_scene* orc_scene_from_arrays_ext(size_t n_prims, const orc_prim* prims, size_t n_quads, const orc_quad* quads,
+                                     size_t n_mats, const orc_material* mats, int builder, uint32_t background,
+                                     const float background_color[3]);
+/* the Cornell box of "The Next Week" (BASELINE.json configs[3]): 5 walls, a light, two rotated boxes as 12 quads */
+orc_scene* orc_scene_cornell_box(void);
 void orc_scene_world(const orc_scene* s, orc_world* out);
 void orc_scene_free(orc_scene* s);
 

@@ -63,6 +63,13 @@ class Scene:
         check(lib().rt_scene_three_spheres(C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def cornell_box(cls):
+        """BASELINE.json configs[3] (not in the reference): 18 quads, one light, black background."""
+        h = C.c_void_p()
+        check(lib().rt_scene_cornell_box(C.byref(h)))
+        return cls(h)
+
     # --- vocabulary ---
     def add_material(self, mtype, albedo, param=0.0, albedo2=None):
         out = C.c_int32()
@@ -81,6 +88,24 @@ class Scene:
 
     def LambertianTexture(self, c1, c2, scale):
         return self.add_material(capi.MAT_LAMBERTIAN_CHECKER, c1, np.float32(1.0) / np.float32(scale), c2)
+
+    def DiffuseLight(self, emit):
+        """diffuse_light of "The Next Week" (extension, not in the reference)."""
+        return self.add_material(capi.MAT_DIFFUSE_LIGHT, emit)
+
+    def MakeQuad(self, Q, u, v, mat):
+        """quad(Q,u,v,mat) of "The Next Week" (extension, not in the reference)."""
+        out = C.c_int32()
+        check(lib().rt_scene_add_quad(self.h, v3(Q), v3(u), v3(v), mat, C.byref(out)))
+        return out.value
+
+    def set_background(self, color=None):
+        """None: the reference's sky gradient; a colour: camera::background of "The Next Week"."""
+        if color is None:
+            check(lib().rt_scene_set_background(self.h, 0, v3((0, 0, 0))))
+        else:
+            check(lib().rt_scene_set_background(self.h, 1, v3(color)))
+        return self
 
     def MakeSphere(self, center, radius, mat):
         out = C.c_int32()
@@ -146,6 +171,10 @@ class Scene:
         w = self.getWorldPtr()
         return (self._arr(w.nodes, w.n_nodes, capi.NODE_DT), self._arr(w.prims, w.n_prims, capi.PRIM_DT),
                 self._arr(w.materials, w.n_materials, capi.MAT_DT))
+
+    def quads(self):
+        w = self.getWorldPtr()
+        return self._arr(w.quads, w.n_quads, capi.QUAD_DT)
 
     def __del__(self):
         try:

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC_DIR, "librt06.so")
 
 RT_OK = 0
 RT_PRIM_MOVING = 0x80000000
-MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LAMBERTIAN_CHECKER = 0, 1, 2, 3
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LAMBERTIAN_CHECKER, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3, 4
 WORLD_BVH, WORLD_LIST, WORLD_NODE_TREE = 0, 1, 2
 CAM_PINHOLE, CAM_DEFOCUS, CAM_MOTION = 0, 1, 2
 
@@ -27,13 +27,17 @@ vec3 = C.c_float * 3
 NODE_DT = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("right", "<i4")])
 PRIM_DT = np.dtype([("c0", "<f4", 3), ("radius", "<f4"), ("c1", "<f4", 3), ("mat", "<u4")])
 MAT_DT = np.dtype([("albedo", "<f4", 3), ("param", "<f4"), ("albedo2", "<f4", 3), ("type", "<u4")])
+QUAD_DT = np.dtype([("Q", "<f4", 3), ("D", "<f4"), ("u", "<f4", 3), ("mat", "<u4"), ("v", "<f4", 3), ("pad0", "<f4"),
+                    ("normal", "<f4", 3), ("pad1", "<f4"), ("w", "<f4", 3), ("pad2", "<f4")])
 
 
 class WorldFlat(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("root", C.c_int32), ("n_nodes", C.c_uint32), ("n_prims", C.c_uint32),
                 ("n_materials", C.c_uint32), ("max_stack", C.c_uint32),
                 ("bounds_min", vec3), ("bounds_max", vec3),
-                ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p)]
+                ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p),
+                ("quads", C.c_void_p), ("n_quads", C.c_uint32), ("background", C.c_uint32),
+                ("background_color", vec3), ("reserved", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -58,7 +62,7 @@ class RtError(RuntimeError):
 SYMBOLS = [
     "rt_last_error", "rt_camera_pinhole", "rt_camera_defocus", "rt_camera_motion",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_material", "rt_scene_add_sphere",
-    "rt_scene_add_moving_sphere", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
+    "rt_scene_add_moving_sphere", "rt_scene_add_quad", "rt_scene_set_background", "rt_scene_cornell_box", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
     "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list", "rt_scene_add_bvh_node",
     "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
     "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
@@ -121,6 +125,9 @@ def lib():
     L.rt_scene_add_material.argtypes = [C.c_void_p, C.c_uint32, vec3, C.c_float, C.c_void_p, P(C.c_int32)]
     L.rt_scene_add_sphere.argtypes = [C.c_void_p, vec3, C.c_float, C.c_int32, P(C.c_int32)]
     L.rt_scene_add_moving_sphere.argtypes = [C.c_void_p, vec3, vec3, C.c_float, C.c_int32, P(C.c_int32)]
+    L.rt_scene_add_quad.argtypes = [C.c_void_p, vec3, vec3, vec3, C.c_int32, P(C.c_int32)]
+    L.rt_scene_set_background.argtypes = [C.c_void_p, C.c_uint32, vec3]
+    L.rt_scene_cornell_box.argtypes = [P(C.c_void_p)]
     L.rt_scene_prim_bounds.argtypes = [C.c_void_p, C.c_int32, vec3, vec3]
     for n in ("rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah", "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list"):
         getattr(L, n).argtypes = [C.c_void_p]

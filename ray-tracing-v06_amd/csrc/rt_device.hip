@@ -51,7 +51,8 @@ struct DevBuf {
 };
 
 struct DeviceScene {
-    DevBuf nodes, prims, mats, blob;
+    DevBuf nodes, prims, mats, blob, quads;
+    bool extended = false;  // quads, an emissive material or a constant background: beyond the reference's feature set
     DeviceWorld dw{};
     PackedSceneRef packed{};  // valid when has_packed
     bool has_packed = false;
@@ -63,10 +64,14 @@ struct DeviceScene {
     int pack(const rt_world_flat* w) {
         has_packed = false;
         regular_boxes = false;
-        if (w->n_prims * 2u >= RT_REF_LEAF || w->n_materials >= (1u << 29)) return RT_OK;  // 16-bit references would not fit
-        auto leaf_ref = [&](uint32_t prim) -> uint32_t {
+        const uint32_t sphere_codes = w->n_prims * 2u;
+        if (sphere_codes + w->n_quads >= RT_REF_LEAF || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // 16-bit references would not fit
+        if (extended && w->kind != RT_WORLD_BVH) return RT_OK;  // quads / lights / background: the LDS kernel takes them in BVH worlds only
+        auto leaf_ref = [&](uint32_t prim) -> uint32_t {  // unified primitive index -> leaf reference
+            if (prim >= w->n_prims) return RT_REF_LEAF | (sphere_codes + (prim - w->n_prims));
             return RT_REF_LEAF | (prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u));
         };
+        auto mat_bits = [&](uint32_t mi, uint32_t moving) -> uint32_t { return mi | (moving << 28) | (w->materials[mi].type << 29); };
         // wide nodes: BVH -> one per inner node, holding BOTH child boxes; bvh_node tree -> one per node, holding its OWN box
         std::vector<int32_t> wide_of(w->n_nodes, -1);
         uint32_t n_inner = 0;
@@ -77,7 +82,7 @@ struct DeviceScene {
             n_inner = w->n_nodes;
         }
         if (n_inner >= RT_REF_LEAF) return RT_OK;
-        size_t n_vec4 = (size_t)n_inner * RT_NODE_VEC4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials;
+        size_t n_vec4 = (size_t)n_inner * RT_NODE_VEC4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials + (size_t)w->n_quads * 5;
         std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));
         if (w->kind == RT_WORLD_BVH) {
             auto ref_of = [&](int32_t node) -> uint32_t {
@@ -124,12 +129,21 @@ struct DeviceScene {
             sph[i] = make_float4(pr.c0[0], pr.c0[1], pr.c0[2], pr.radius);
             uint32_t mi = pr.mat & ~RT_PRIM_MOVING;
             uint32_t moving = (pr.mat & RT_PRIM_MOVING) ? 1u : 0u;
-            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(mi | (moving << 29) | (w->materials[mi].type << 30)));
+            ext[i] = make_float4(pr.c1[0], pr.c1[1], pr.c1[2], __uint_as_float_host(mat_bits(mi, moving)));
         }
         float4* m16 = ext + w->n_prims;
         for (uint32_t i = 0; i < w->n_materials; i++) {
             const rt_material& m = w->materials[i];
             m16[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
+        }
+        float4* qd = m16 + w->n_materials;
+        for (uint32_t i = 0; i < w->n_quads; i++) {
+            const rt_quad& q = w->quads[i];
+            qd[5 * i + 0] = make_float4(q.Q[0], q.Q[1], q.Q[2], q.D);
+            qd[5 * i + 1] = make_float4(q.u[0], q.u[1], q.u[2], __uint_as_float_host(mat_bits(q.mat, 0u)));
+            qd[5 * i + 2] = make_float4(q.v[0], q.v[1], q.v[2], 0.0f);
+            qd[5 * i + 3] = make_float4(q.normal[0], q.normal[1], q.normal[2], 0.0f);
+            qd[5 * i + 4] = make_float4(q.w[0], q.w[1], q.w[2], 0.0f);
         }
         HIP_TRY(blob.upload(host.data(), n_vec4 * sizeof(uint4)));
         packed.blob = blob.as<uint4>();
@@ -137,8 +151,12 @@ struct DeviceScene {
         packed.off_spheres = n_inner * RT_NODE_VEC4;
         packed.off_extra = n_inner * RT_NODE_VEC4 + w->n_prims;
         packed.off_mats = n_inner * RT_NODE_VEC4 + w->n_prims * 2;
+        packed.off_quads = n_inner * RT_NODE_VEC4 + w->n_prims * 2 + w->n_materials;
+        packed.sphere_codes = sphere_codes;
+        packed.background = w->background;
+        for (int k = 0; k < 3; k++) packed.background_color[k] = w->background_color[k];
         packed.n_inner = n_inner;
-        packed.n_codes = w->n_prims * 2u;
+        packed.n_codes = sphere_codes + w->n_quads;
         packed.n_prims = w->n_prims;
         packed.stack_cap = true_stack ? true_stack : 1u;
         packed.mats = mats.as<rt_material>();
@@ -148,21 +166,30 @@ struct DeviceScene {
     int upload(const rt_world_flat* w) {
         if (!w) return rt_fail(RT_ERR_INVALID, "null world");
         if (w->kind > RT_WORLD_NODE_TREE) return rt_fail(RT_ERR_INVALID, "unknown world kind %u", w->kind);
-        if (w->n_prims == 0 || !w->prims) return rt_fail(RT_ERR_INVALID, "world has no primitives");
+        if ((w->n_prims == 0 || !w->prims) && (w->n_quads == 0 || !w->quads)) return rt_fail(RT_ERR_INVALID, "world has no primitives");
+        if ((w->n_prims && !w->prims) || (w->n_quads && !w->quads)) return rt_fail(RT_ERR_INVALID, "world primitive array is null");
+        if (w->background > 1) return rt_fail(RT_ERR_INVALID, "unknown background mode %u", w->background);
+        if (w->n_quads && w->kind == RT_WORLD_NODE_TREE) return rt_fail(RT_ERR_INVALID, "bvh_node trees take spheres only");
+        const uint32_t n_all = w->n_prims + w->n_quads;
         if (w->n_materials == 0 || !w->materials) return rt_fail(RT_ERR_INVALID, "world has no materials");
         if (w->kind != RT_WORLD_LIST && (w->n_nodes == 0 || !w->nodes)) return rt_fail(RT_ERR_INVALID, "BVH world has no nodes");
         if (w->max_stack > RT_MAX_STACK) return rt_fail(RT_ERR_STACK, "world needs a %u-entry traversal stack; limit %d", w->max_stack, RT_MAX_STACK);
         // validate every index the kernels will follow: a bad index is a GPU fault, not an error code
         for (uint32_t i = 0; i < w->n_prims; i++)
             if ((w->prims[i].mat & ~RT_PRIM_MOVING) >= w->n_materials) return rt_fail(RT_ERR_INVALID, "primitive %u: material index out of range", i);
-        for (uint32_t i = 0; i < w->n_materials; i++)
-            if (w->materials[i].type > RT_MAT_LAMBERTIAN_CHECKER) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
+        for (uint32_t i = 0; i < w->n_quads; i++)
+            if (w->quads[i].mat >= w->n_materials) return rt_fail(RT_ERR_INVALID, "quad %u: material index out of range", i);
+        extended = w->n_quads != 0 || w->background != 0;
+        for (uint32_t i = 0; i < w->n_materials; i++) {
+            if (w->materials[i].type > RT_MAT_DIFFUSE_LIGHT) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
+            if (w->materials[i].type == RT_MAT_DIFFUSE_LIGHT) extended = true;
+        }
         if (w->kind == RT_WORLD_BVH) {
             if (w->root < 0 || (uint32_t)w->root >= w->n_nodes) return rt_fail(RT_ERR_INVALID, "BVH root out of range");
             for (uint32_t i = 0; i < w->n_nodes; i++) {
                 const rt_bvh_node& n = w->nodes[i];
                 if (n.left == -1) {
-                    if (n.right < 0 || (uint32_t)n.right >= w->n_prims) return rt_fail(RT_ERR_INVALID, "BVH leaf %u: primitive index out of range", i);
+                    if (n.right < 0 || (uint32_t)n.right >= n_all) return rt_fail(RT_ERR_INVALID, "BVH leaf %u: primitive index out of range", i);
                 } else if (n.left < 0 || (uint32_t)n.left >= w->n_nodes || n.right < 0 || (uint32_t)n.right >= w->n_nodes || (uint32_t)n.left == i || (uint32_t)n.right == i)
                     return rt_fail(RT_ERR_INVALID, "BVH node %u: child index out of range", i);
             }
@@ -200,11 +227,15 @@ struct DeviceScene {
         HIP_TRY(nodes.upload(w->nodes, sizeof(rt_bvh_node) * (size_t)w->n_nodes));
         HIP_TRY(prims.upload(w->prims, sizeof(rt_prim) * (size_t)w->n_prims));
         HIP_TRY(mats.upload(w->materials, sizeof(rt_material) * (size_t)w->n_materials));
+        HIP_TRY(quads.upload(w->quads, sizeof(rt_quad) * (size_t)w->n_quads));
         dw.kind = w->kind; dw.root = w->root;
         dw.n_nodes = w->n_nodes; dw.n_prims = w->n_prims; dw.n_mats = w->n_materials;
         dw.bmin = mk3(w->bounds_min[0], w->bounds_min[1], w->bounds_min[2]);
         dw.bmax = mk3(w->bounds_max[0], w->bounds_max[1], w->bounds_max[2]);
         dw.nodes = nodes.as<rt_bvh_node>(); dw.prims = prims.as<rt_prim>(); dw.mats = mats.as<rt_material>();
+        dw.quads = quads.as<rt_quad>(); dw.n_quads = w->n_quads;
+        dw.background = w->background;
+        dw.background_color = mk3(w->background_color[0], w->background_color[1], w->background_color[2]);
         return pack(w);
     }
 };
@@ -273,7 +304,9 @@ struct rt_renderer {
             if (stream_lds_bytes > lds_per_cu || scene.packed.n_inner >= 0x8000u || scene.packed.n_codes >= 0x8000u) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
-        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes) ? 3u : 2u) : 1u;
+        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && !scene.extended) ? 3u : 2u) : 1u;
+        if (want >= 3 && scene.extended)
+            return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 render the reference's feature set only (no quads / lights / constant background): use variant 2");
         if (want >= 3 && scene.dw.kind != RT_WORLD_BVH)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need an RT_WORLD_BVH world (a HittableList / bvh_node world runs on variant 2)");
         if (want >= 2 && !can_stream)
@@ -310,6 +343,7 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
+        if (scene.extended) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true>);
         if (scene.dw.kind == RT_WORLD_LIST) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST>);
         if (scene.dw.kind == RT_WORLD_NODE_TREE) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_NODE_TREE>);
         if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768>);
@@ -633,7 +667,7 @@ extern "C" int rt_probe_scatter(int device, uint64_t seed, size_t n, const rt_ma
         return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: null argument");
     if (n == 0) return RT_OK;
     for (size_t i = 0; i < n; i++)
-        if (mats[i].type > RT_MAT_LAMBERTIAN_CHECKER) return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: case %zu: unknown material type", i);
+        if (mats[i].type > RT_MAT_DIFFUSE_LIGHT) return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: case %zu: unknown material type", i);
     int rc = select_device(device);
     if (rc != RT_OK) return rc;
     DevBuf m, r, d, nn, k, s, orr, a, dr;

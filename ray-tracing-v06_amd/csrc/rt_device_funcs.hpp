@@ -18,6 +18,11 @@ struct DeviceWorld {
     const rt_bvh_node* nodes;
     const rt_prim* prims;
     const rt_material* mats;
+    // extension beyond the reference: quads (primitive index >= n_prims), constant background
+    const rt_quad* quads;
+    uint32_t n_quads;
+    uint32_t background;
+    f3 background_color;
 };
 
 // RayPayload (ray_data.cuh:33-40) with Sphere::TraceRecord (SphereHittable.cuh:38-41) unpacked
@@ -73,6 +78,34 @@ RT_HD bool prim_closest_intersection(const rt_prim& p, int32_t idx, const Ray& r
     return true;
 }
 
+// quad::hit of "Ray Tracing: The Next Week" in the reference's conventions: t >= 0 accepted (no t_min: the origin is
+// offset instead, Renderer.cu:175), `t >= rec.distance` rejects; the stored normal faces AGAINST the ray (two-sided).
+RT_HD bool quad_closest_intersection(f3 Q, float D, f3 u, f3 v, f3 n, f3 w, uint32_t mat, int32_t unified, const Ray& ray, HitRec& rec) {
+    float denom = dot(n, ray.d);
+    if (fabsf(denom) < 1e-8f) return false;
+    float t = (D - dot(n, ray.o)) / denom;
+    if (t < 0.0f) return false;
+    if (t >= rec.distance) return false;
+    f3 planar = ray_at(ray, t) - Q;
+    float alpha = dot(w, cross(planar, v));
+    float beta = dot(w, cross(u, planar));
+    if (!(alpha >= 0.0f && alpha <= 1.0f && beta >= 0.0f && beta <= 1.0f)) return false;
+    rec.mat = mat;
+    rec.distance = t;
+    rec.prim = unified;
+    rec.normal = (dot(ray.d, n) > 0) ? -n : n;
+    return true;
+}
+
+__device__ inline bool any_prim_closest_intersection(const DeviceWorld& w, int32_t idx, const Ray& ray, HitRec& rec) {
+    if ((uint32_t)idx >= w.n_prims) {
+        const rt_quad& q = w.quads[(uint32_t)idx - w.n_prims];
+        return quad_closest_intersection(mk3(q.Q[0], q.Q[1], q.Q[2]), q.D, mk3(q.u[0], q.u[1], q.u[2]), mk3(q.v[0], q.v[1], q.v[2]),
+                                         mk3(q.normal[0], q.normal[1], q.normal[2]), mk3(q.w[0], q.w[1], q.w[2]), q.mat, idx, ray, rec);
+    }
+    return prim_closest_intersection(w.prims[idx], idx, ray, rec);
+}
+
 RT_HD bool node_box(const rt_bvh_node& n, const Ray& ray, float maxd, float& dist) {
     return aabb_intersects(mk3(n.min[0], n.min[1], n.min[2]), mk3(n.max[0], n.max[1], n.max[2]), ray, maxd, dist);
 }
@@ -92,7 +125,7 @@ __device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray&
         const rt_bvh_node& node = w.nodes[idx];
         int32_t left_idx = node.left, right_idx = node.right;
         if (left_idx == -1) {
-            hit_any |= prim_closest_intersection(w.prims[right_idx], right_idx, ray, rec);
+            hit_any |= any_prim_closest_intersection(w, right_idx, ray, rec);
             continue;
         }
         float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
@@ -113,8 +146,8 @@ __device__ inline bool list_closest_intersection(const DeviceWorld& w, const Ray
     float d;
     if (!aabb_intersects(w.bmin, w.bmax, ray, rec.distance, d)) return false;
     bool hit_any = false;
-    for (uint32_t i = 0; i < w.n_prims; i++)
-        if (prim_closest_intersection(w.prims[i], (int32_t)i, ray, rec)) hit_any = true;
+    for (uint32_t i = 0; i < w.n_prims + w.n_quads; i++)
+        if (any_prim_closest_intersection(w, (int32_t)i, ray, rec)) hit_any = true;
     return hit_any;
 }
 
@@ -175,6 +208,7 @@ RT_HD f3 checker_value(f3 even, f3 odd, float inv_scale, f3 pos) {
 // DielectricAbstract (:115-143), LambertianTexture (:27-40)
 RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRec& rec, Rng& rng, Ray& out, f3& attenuation) {
     f3 normal = rec.normal;
+    if (m.type == RT_MAT_DIFFUSE_LIGHT) return false;  // diffuse_light of "The Next Week": emits, never scatters
     const f3 albedo = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
     const f3 albedo2 = mk3(m.albedo2[0], m.albedo2[1], m.albedo2[2]);
     if (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LAMBERTIAN_CHECKER) {
@@ -231,25 +265,35 @@ RT_HD Ray camera_sample_ray(const rt_camera& c, float s, float t, Rng& rng) {
     return r;
 }
 
-// sample_world, main/src/Renderer.cu:139-181
+// sample_world, main/src/Renderer.cu:139-181.  The emission / background hooks are the reference's own commented
+// placeholders (`accum_radiance`, Renderer.cu:142,152,157,163,179); with no emissive material and background 0 this
+// is exactly the live function.
 __device__ inline f3 sample_world(const DeviceWorld& w, Ray cur_ray, uint32_t max_depth, Rng& rng) {
     f3 accum_attenuation = mk3(1.0f);
+    f3 accum_radiance = mk3(0.0f);
     for (uint32_t i = 0; i < max_depth; i++) {
         HitRec rec;
         rec.distance = RT_MISS_DIST; rec.normal = mk3(0.0f); rec.prim = -1; rec.mat = 0;
         if (!world_closest_intersection(w, cur_ray, rec)) {
-            float t = normalize(cur_ray.d).y * 0.5f + 0.5f;
-            f3 sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
-            return accum_attenuation * sky;
+            f3 sky;
+            if (w.background == 1u) {
+                sky = w.background_color;
+            } else {
+                float t = normalize(cur_ray.d).y * 0.5f + 0.5f;
+                sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
+            }
+            return accum_attenuation * sky + accum_radiance;
         }
+        const rt_material& m = w.mats[rec.mat];
+        if (m.type == RT_MAT_DIFFUSE_LIGHT) accum_radiance = accum_radiance + accum_attenuation * mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
         Ray scattered;
         f3 attenuation;
-        if (!material_scatter(w.mats[rec.mat], cur_ray, rec, rng, scattered, attenuation)) return mk3(0.0f);
+        if (!material_scatter(m, cur_ray, rec, rng, scattered, attenuation)) return accum_radiance;
         accum_attenuation = accum_attenuation * attenuation;
         cur_ray = scattered;
         cur_ray.o = cur_ray.o + cur_ray.d * 0.001f;
     }
-    return mk3(0.0f);
+    return accum_radiance;
 }
 
 // pixel centre in NDC, Renderer.cu:188-192

@@ -114,6 +114,9 @@ static Box prim_bounds(const rt_prim& p) {
 // ---------------------------------------------------------------------------------------------
 struct rt_scene {
     std::vector<rt_prim> prims;
+    std::vector<rt_quad> quads;
+    uint32_t background = 0;
+    float background_color[3] = {0.0f, 0.0f, 0.0f};
     std::vector<rt_material> mats;
     std::vector<rt_bvh_node> nodes;       // world nodes (BVH or bvh_node tree)
     std::vector<rt_bvh_node> tree_nodes;  // bvh_node objects created by rt_scene_add_bvh_node
@@ -134,7 +137,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) { delete s; }
 extern "C" int rt_scene_add_material(rt_scene* s, uint32_t type, const float albedo[3], float param,
                                      const float albedo2[3], int32_t* out_id) {
     if (!s || !albedo) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: null argument");
-    if (type > RT_MAT_LAMBERTIAN_CHECKER) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: unknown material type %u", type);
+    if (type > RT_MAT_DIFFUSE_LIGHT) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: unknown material type %u", type);
     rt_material m;
     std::memset(&m, 0, sizeof(m));
     st3(m.albedo, ld3(albedo));
@@ -172,11 +175,54 @@ extern "C" int rt_scene_prim_bounds(const rt_scene* s, int32_t prim, float out_m
     return RT_OK;
 }
 
+// ---- quads (not in the reference; "Ray Tracing: The Next Week" quad(Q,u,v)) -------------------------
+static void quad_finalize(rt_quad& q) {
+    f3 n = cross(ld3(q.u), ld3(q.v));
+    f3 normal = normalize(n);
+    st3(q.normal, normal);
+    q.D = dot(normal, ld3(q.Q));
+    st3(q.w, n / dot(n, n));
+    q.pad0 = q.pad1 = q.pad2 = 0.0f;
+}
+static Box box_of_points(f3 a, f3 b) { return Box{glm_min(a, b), glm_max(a, b)}; }
+// bbox = box(Q, Q+u+v) U box(Q+u, Q+v), every axis padded to at least 0.0001 (the book's aabb::pad_to_minimums)
+static Box quad_bounds(const rt_quad& q) {
+    f3 Q = ld3(q.Q), u = ld3(q.u), v = ld3(q.v);
+    Box b = box_union(box_of_points(Q, Q + u + v), box_of_points(Q + u, Q + v));
+    const float delta = 0.0001f;
+    if (b.mx.x - b.mn.x < delta) { b.mn.x -= delta / 2; b.mx.x += delta / 2; }
+    if (b.mx.y - b.mn.y < delta) { b.mn.y -= delta / 2; b.mx.y += delta / 2; }
+    if (b.mx.z - b.mn.z < delta) { b.mn.z -= delta / 2; b.mx.z += delta / 2; }
+    return b;
+}
+extern "C" int rt_scene_add_quad(rt_scene* s, const float Q[3], const float u[3], const float v[3], int32_t mat, int32_t* out_quad) {
+    if (!s || !Q || !u || !v) return rt_fail(RT_ERR_INVALID, "rt_scene_add_quad: null argument");
+    if (mat < 0 || (size_t)mat >= s->mats.size()) return rt_fail(RT_ERR_INVALID, "rt_scene_add_quad: material index %d out of range", mat);
+    rt_quad q;
+    std::memset(&q, 0, sizeof(q));
+    st3(q.Q, ld3(Q)); st3(q.u, ld3(u)); st3(q.v, ld3(v));
+    q.mat = (uint32_t)mat;
+    quad_finalize(q);
+    s->quads.push_back(q);
+    s->world_set = false;
+    if (out_quad) *out_quad = (int32_t)s->quads.size() - 1;
+    return RT_OK;
+}
+extern "C" int rt_scene_set_background(rt_scene* s, uint32_t mode, const float color[3]) {
+    if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_background: null scene");
+    if (mode > 1) return rt_fail(RT_ERR_INVALID, "rt_scene_set_background: unknown mode %u", mode);
+    s->background = mode;
+    if (color) st3(s->background_color, ld3(color));
+    return RT_OK;
+}
+
 // ---- BVH_Handle::Factory (rt_engine/geometry/BVH.cu:156-384) --------------------------------
 namespace {
 struct Item {
     Box b;
+    bool is_quad;
     rt_prim p;
+    rt_quad q;
 };
 struct Builder {
     std::vector<Item> arr;
@@ -286,16 +332,28 @@ uint32_t leaf_depth(const std::vector<rt_bvh_node>& nodes, int32_t idx) {
 
 static int build_bvh(rt_scene* s, int builder) {
     if (!s) return rt_fail(RT_ERR_INVALID, "build_bvh: null scene");
-    if (s->prims.empty()) return rt_fail(RT_ERR_INVALID, "build_bvh: scene has no primitives");
+    if (s->prims.empty() && s->quads.empty()) return rt_fail(RT_ERR_INVALID, "build_bvh: scene has no primitives");
     s->nodes.clear();
     Builder B(s->nodes);
-    B.arr.reserve(s->prims.size());
-    for (const rt_prim& p : s->prims) B.arr.push_back(Item{prim_bounds(p), p});
+    B.arr.reserve(s->prims.size() + s->quads.size());
+    for (const rt_prim& p : s->prims) B.arr.push_back(Item{prim_bounds(p), false, p, rt_quad{}});
+    for (const rt_quad& q : s->quads) B.arr.push_back(Item{quad_bounds(q), true, rt_prim{}, q});
     int32_t root;
     if (builder == 0) root = B.rec1(0, (int)B.arr.size());
     else if (builder == 1) root = B.rec2(0, (int)B.arr.size());
     else root = B.bottom_up();
-    for (size_t i = 0; i < B.arr.size(); i++) s->prims[i] = B.arr[i].p;  // hittables[] = arr order, BVH.cu:174-177
+    // hittables[] = arr order (BVH.cu:174-177), kept per kind: spheres first, then quads; leaf indices are remapped
+    {
+        std::vector<int32_t> unified(B.arr.size());
+        const size_t ns = s->prims.size();
+        size_t si = 0, qi = 0;
+        for (size_t i = 0; i < B.arr.size(); i++) {
+            if (B.arr[i].is_quad) { s->quads[qi] = B.arr[i].q; unified[i] = (int32_t)(ns + qi); qi++; }
+            else { s->prims[si] = B.arr[i].p; unified[i] = (int32_t)si; si++; }
+        }
+        for (rt_bvh_node& n : s->nodes)
+            if (n.left == -1) n.right = unified[n.right];
+    }
     s->kind = RT_WORLD_BVH;
     s->root = root;
     s->max_stack = leaf_depth(s->nodes, root) + 1;
@@ -312,13 +370,14 @@ extern "C" int rt_scene_build_bvh_bottomup(rt_scene* s) { return build_bvh(s, 2)
 
 extern "C" int rt_scene_set_world_list(rt_scene* s) {
     if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_world_list: null scene");
-    if (s->prims.empty()) return rt_fail(RT_ERR_INVALID, "rt_scene_set_world_list: scene has no primitives");
+    if (s->prims.empty() && s->quads.empty()) return rt_fail(RT_ERR_INVALID, "rt_scene_set_world_list: scene has no primitives");
     s->nodes.clear();
     s->kind = RT_WORLD_LIST;
     s->root = 0;
     s->max_stack = 0;
     Box b = box_empty();
     for (const rt_prim& p : s->prims) b = box_union(b, prim_bounds(p));  // world_bounds += handle.getBounds(), Scenes.cu:61
+    for (const rt_quad& q : s->quads) b = box_union(b, quad_bounds(q));
     s->bounds = b;
     s->world_set = true;
     return RT_OK;
@@ -351,6 +410,7 @@ static uint32_t tree_depth(const rt_scene* s, int32_t ref, uint32_t guard) {
 extern "C" int rt_scene_set_world_node_tree(rt_scene* s, int32_t root_ref) {
     if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_world_node_tree: null scene");
     if (!ref_valid(s, root_ref)) return rt_fail(RT_ERR_INVALID, "rt_scene_set_world_node_tree: bad root reference");
+    if (!s->quads.empty()) return rt_fail(RT_ERR_INVALID, "rt_scene_set_world_node_tree: bvh_node trees take spheres only");
     s->nodes = s->tree_nodes;
     s->kind = RT_WORLD_NODE_TREE;
     s->root = root_ref;
@@ -375,8 +435,12 @@ extern "C" int rt_scene_get_flat(const rt_scene* s, rt_world_flat* out) {
     out->max_stack = s->max_stack;
     st3(out->bounds_min, s->bounds.mn); st3(out->bounds_max, s->bounds.mx);
     out->nodes = s->nodes.empty() ? nullptr : s->nodes.data();
-    out->prims = s->prims.data();
+    out->prims = s->prims.empty() ? nullptr : s->prims.data();
     out->materials = s->mats.data();
+    out->quads = s->quads.empty() ? nullptr : s->quads.data();
+    out->n_quads = (uint32_t)s->quads.size();
+    out->background = s->background;
+    st3(out->background_color, ld3(s->background_color));
     return RT_OK;
 }
 
@@ -458,6 +522,48 @@ extern "C" int rt_scene_three_spheres(rt_scene** out) {
     add(s, mk3(-1, 0, -1), mk3(-1, 0, -1), 0.4f, false, RT_MAT_DIELECTRIC, mk3(1.0f), 1.0f / 1.5f);
     add(s, mk3(1, 0, -1), mk3(1, 0, -1), 0.5f, false, RT_MAT_METAL, mk3(0.8f, 0.6f, 0.2f), 1.0f);
     int rc = rt_scene_set_world_list(s);
+    if (rc != RT_OK) { delete s; return rc; }
+    *out = s;
+    return RT_OK;
+}
+
+// ---- Cornell box of "Ray Tracing: The Next Week" (BASELINE.json configs[3]) ------------------------------
+static void cornell_quad(rt_scene* s, f3 Q, f3 u, f3 v, int32_t mat) {
+    float a[3], b[3], c[3];
+    st3(a, Q); st3(b, u); st3(c, v);
+    rt_scene_add_quad(s, a, b, c, mat, nullptr);
+}
+static f3 rot_y(f3 p, float c, float sn) { return mk3(c * p.x + sn * p.z, p.y, -sn * p.x + c * p.z); }
+// box(a,b) of the book as 6 quads, rotated about y and translated on the host (the book uses rotate_y / translate instances)
+static void cornell_box(rt_scene* s, f3 a, f3 b, float degrees, f3 offset, int32_t mat) {
+    f3 mn = glm_min(a, b), mx = glm_max(a, b);
+    f3 dx = mk3(mx.x - mn.x, 0, 0), dy = mk3(0, mx.y - mn.y, 0), dz = mk3(0, 0, mx.z - mn.z);
+    float rad = radians(degrees), c = cosf(rad), sn = sinf(rad);
+    f3 Qs[6] = {mk3(mn.x, mn.y, mx.z), mk3(mx.x, mn.y, mx.z), mk3(mx.x, mn.y, mn.z), mk3(mn.x, mn.y, mn.z), mk3(mn.x, mx.y, mx.z), mk3(mn.x, mn.y, mn.z)};
+    f3 us[6] = {dx, -dz, -dx, dz, dx, dx};
+    f3 vs[6] = {dy, dy, dy, dy, -dz, dz};
+    for (int k = 0; k < 6; k++) cornell_quad(s, rot_y(Qs[k], c, sn) + offset, rot_y(us[k], c, sn), rot_y(vs[k], c, sn), mat);
+}
+extern "C" int rt_scene_cornell_box(rt_scene** out) {
+    if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_cornell_box: null out");
+    rt_scene* s = new rt_scene();
+    const float red[3] = {0.65f, 0.05f, 0.05f}, white[3] = {0.73f, 0.73f, 0.73f}, green[3] = {0.12f, 0.45f, 0.15f}, light[3] = {15.0f, 15.0f, 15.0f};
+    int32_t m_red, m_white, m_green, m_light;
+    rt_scene_add_material(s, RT_MAT_LAMBERTIAN, red, 0.0f, nullptr, &m_red);
+    rt_scene_add_material(s, RT_MAT_LAMBERTIAN, white, 0.0f, nullptr, &m_white);
+    rt_scene_add_material(s, RT_MAT_LAMBERTIAN, green, 0.0f, nullptr, &m_green);
+    rt_scene_add_material(s, RT_MAT_DIFFUSE_LIGHT, light, 0.0f, nullptr, &m_light);
+    cornell_quad(s, mk3(555, 0, 0), mk3(0, 555, 0), mk3(0, 0, 555), m_green);
+    cornell_quad(s, mk3(0, 0, 0), mk3(0, 555, 0), mk3(0, 0, 555), m_red);
+    cornell_quad(s, mk3(343, 554, 332), mk3(-130, 0, 0), mk3(0, 0, -105), m_light);
+    cornell_quad(s, mk3(0, 0, 0), mk3(555, 0, 0), mk3(0, 0, 555), m_white);
+    cornell_quad(s, mk3(555, 555, 555), mk3(-555, 0, 0), mk3(0, 0, -555), m_white);
+    cornell_quad(s, mk3(0, 0, 555), mk3(555, 0, 0), mk3(0, 555, 0), m_white);
+    cornell_box(s, mk3(0, 0, 0), mk3(165, 330, 165), 15.0f, mk3(265, 0, 295), m_white);
+    cornell_box(s, mk3(0, 0, 0), mk3(165, 165, 165), -18.0f, mk3(130, 0, 65), m_white);
+    const float black[3] = {0.0f, 0.0f, 0.0f};
+    rt_scene_set_background(s, 1, black);
+    int rc = rt_scene_build_bvh_topdown(s);
     if (rc != RT_OK) { delete s; return rc; }
     *out = s;
     return RT_OK;

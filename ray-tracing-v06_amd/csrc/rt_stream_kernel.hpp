@@ -47,6 +47,7 @@
 //   bit 15 clear: wide-node index;  bit 15 set: leaf, code = ref & 0x7fff = prim * 2 + is_moving.
 // The same encoding travels through the per-lane LDS stack as 16-bit entries.
 #define RT_REF_LEAF 0x8000u
+#define RT_MAT_INDEX_MASK 0x0fffffffu  // matbits: index (28 bits) | moving << 28 | type << 29
 struct WideNode {
     float lmin[3], lmax[3], rmin[3], rmax[3];
     uint32_t lref, rref;
@@ -54,13 +55,18 @@ struct WideNode {
 };
 static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
 
-// LDS image, in 16-B units:  [wide nodes (RT_NODE_VEC4 each) | spheres (c0, r) | extra (c1, mat | moving << 29 | type << 30) | mats16 (albedo, param)]
+// LDS image, in 16-B units:  [wide nodes (RT_NODE_VEC4 each) | spheres (c0, r) | extra (c1, matbits) | mats16 (albedo, param) |
+//                              quads (5 each: Q,D | u,matbits | v | normal | w)],   matbits = material index | moving << 28 | type << 29
 struct PackedSceneRef {
     const uint4* blob;
     uint32_t blob_vec4;      // number of 16-B units to stage into LDS
     uint32_t off_spheres;
     uint32_t off_extra;
     uint32_t off_mats;
+    uint32_t off_quads;
+    uint32_t sphere_codes;   // leaf codes below this are spheres (prim * 2 + is_moving); code - sphere_codes is a quad index
+    uint32_t background;     // 0 = reference sky gradient, 1 = background_color
+    float background_color[3];
     uint32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
@@ -108,7 +114,11 @@ enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
 // WORLD: RT_WORLD_BVH (default), RT_WORLD_LIST (HittableList: bounds pre-test, then every sphere in order;
 //        a reference is RT_REF_LEAF | primitive index and the "traversal" is the leaf phase alone) or
 //        RT_WORLD_NODE_TREE (bvh_node: a node is tested against ITS OWN box when visited, then left, then right).
-template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH>
+// EXT = true: the scene uses features the reference does not have (quads, diffuse lights, a constant background):
+//        leaf codes >= sphere_codes are quads, emitted radiance is accumulated along the path (the reference's
+//        commented `accum_radiance`), the miss colour may be a constant.  A separate instantiation, so the
+//        reference-feature kernels carry none of it.
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, bool EXT = false>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -123,6 +133,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
     const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
     const float4* mats16 = reinterpret_cast<const float4*>(lds + p.scene.off_mats);
+    const float4* quads = reinterpret_cast<const float4*>(lds + p.scene.off_quads);
     // per-lane traversal stack of 16-bit references.  Entry k of this lane is stack[k * 64].
     uint16_t* stack = reinterpret_cast<uint16_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
 
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     f3 inv_d = mk3(0.0f);   // RN(1/d) of a regular ray (EXACT == false)
     bool regular = false;
     f3 atten = mk3(0.0f);
+    f3 accum_rad = mk3(0.0f);  // EXT only: radiance emitted along the path so far
     Rng rng;
     rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
     float rec_t = RT_MISS_DIST;
@@ -185,6 +197,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             cur = stack[sp * 64u];    \
         }                             \
     } while (0)
+#define RT_EMIT_DARK() RT_EMIT(EXT ? accum_rad.x : 0.0f, EXT ? accum_rad.y : 0.0f, EXT ? accum_rad.z : 0.0f)
 #define RT_EMIT(rx, ry, rz)                                   \
     do {                                                      \
         float* o_ = p.samples + (size_t)out_idx * 3u;         \
@@ -270,12 +283,25 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot((state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u) == 0ull)) {
                 if (at_leaf) {
                     uint32_t code = cur & 0x7fffu;   // BVH / tree: prim * 2 + is_moving;  list: prim
+                    if (EXT && code >= p.scene.sphere_codes) {
+                        // quad::hit ("The Next Week"), reference conventions: see quad_closest_intersection()
+                        const float4* qd = quads + (code - p.scene.sphere_codes) * 5u;
+                        float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a3 = qd[3], a4 = qd[4];
+                        HitRec tmp;
+                        tmp.distance = rec_t; tmp.normal = mk3(0.0f); tmp.prim = -1; tmp.mat = 0;
+                        if (quad_closest_intersection(mk3(a0.x, a0.y, a0.z), a0.w, mk3(a1.x, a1.y, a1.z), mk3(a2.x, a2.y, a2.z),
+                                                      mk3(a3.x, a3.y, a3.z), mk3(a4.x, a4.y, a4.z), 0u, 0, ray, tmp)) {
+                            rec_t = tmp.distance;
+                            rec_code = (int32_t)code;
+                        }
+                        RT_POP();
+                    } else {
                     uint32_t prim = (WORLD == RT_WORLD_LIST) ? code : code >> 1;
                     float4 sph = spheres[prim];
                     f3 center = mk3(sph.x, sph.y, sph.z);
                     if (WORLD == RT_WORLD_LIST) {
                         float4 ex = extra[prim];
-                        const uint32_t moving = (__float_as_uint(ex.w) >> 29) & 1u;
+                        const uint32_t moving = (__float_as_uint(ex.w) >> 28) & 1u;
                         code = prim * 2u + moving;
                         if (moving) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
                     } else if (code & 1u) {
@@ -293,6 +319,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     } else {
                         RT_POP();
                     }
+                    }
                 }
             }
         }
@@ -305,34 +332,57 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
         if (state == ST_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
             if (rec_code < 0) {
-                float t = normalize(ray.d).y * 0.5f + 0.5f;
-                f3 sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
+                f3 sky;
+                if (EXT && p.scene.background == 1u) {
+                    sky = mk3(p.scene.background_color[0], p.scene.background_color[1], p.scene.background_color[2]);
+                } else {
+                    float t = normalize(ray.d).y * 0.5f + 0.5f;
+                    sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
+                }
                 f3 rad = atten * sky;
+                if (EXT) rad = rad + accum_rad;
                 RT_EMIT(rad.x, rad.y, rad.z);
-            } else if (depth + 1u >= p.max_depth) {
+            } else if (!EXT && depth + 1u >= p.max_depth) {
                 RT_EMIT(0.0f, 0.0f, 0.0f);  // the scatter of the last allowed bounce cannot reach the sky: result is 0
             } else {
                 // ---- what every material needs: hit point, outward normal, material record ----
-                uint32_t prim = (uint32_t)rec_code >> 1;
-                float4 sph = spheres[prim];
-                float4 ex = extra[prim];
-                f3 center = mk3(sph.x, sph.y, sph.z);
-                if ((uint32_t)rec_code & 1u) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
                 const f3 hit_p = ray_at(ray, rec_t);
-                f3 normal = (hit_p - center) / sph.w;  // SphereHittable.cu:64 / :100
-                const uint32_t mat_bits = __float_as_uint(ex.w);
-                const uint32_t mtype = mat_bits >> 30;
-                const float4 mrec = mats16[mat_bits & 0x1fffffffu];
+                f3 normal;
+                uint32_t mat_bits;
+                if (EXT && (uint32_t)rec_code >= p.scene.sphere_codes) {
+                    const float4* qd = quads + ((uint32_t)rec_code - p.scene.sphere_codes) * 5u;
+                    float4 a1 = qd[1], a3 = qd[3];
+                    normal = mk3(a3.x, a3.y, a3.z);
+                    if (dot(ray.d, normal) > 0) normal = -normal;  // the book's set_face_normal: a quad is two-sided
+                    mat_bits = __float_as_uint(a1.w);
+                } else {
+                    uint32_t prim = (uint32_t)rec_code >> 1;
+                    float4 sph = spheres[prim];
+                    float4 ex = extra[prim];
+                    f3 center = mk3(sph.x, sph.y, sph.z);
+                    if ((uint32_t)rec_code & 1u) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                    normal = (hit_p - center) / sph.w;  // SphereHittable.cu:64 / :100
+                    mat_bits = __float_as_uint(ex.w);
+                }
+                const uint32_t mtype = mat_bits >> 29;
+                const float4 mrec = mats16[mat_bits & RT_MAT_INDEX_MASK];
                 f3 albedo = mk3(mrec.x, mrec.y, mrec.z);
                 const float mparam = mrec.w;
 
+                // EXT: emitted radiance of a diffuse light is added before the scatter decision (accum_radiance of
+                // Renderer.cu:157-163); a light never scatters; the last allowed bounce still collects emission.
+                bool path_over = false;
+                if (EXT) {
+                    if (mtype == RT_MAT_DIFFUSE_LIGHT) { accum_rad = accum_rad + atten * albedo; path_over = true; }
+                    if (depth + 1u >= p.max_depth) path_over = true;
+                }
                 // ---- Scatter (cu_materials.cuh:52-64 / 77-95 / 115-143 / 27-40); per-lane arithmetic is
                 // ---- material_scatter()'s, expression by expression.
                 const bool is_diel = (mtype == RT_MAT_DIELECTRIC);
                 f3 unit_dir = mk3(0.0f);
                 float ior_ratio = 0.0f, reflect_prob = 0.0f;
                 bool must_reflect = false;
-                if (is_diel) {
+                if (is_diel && !path_over) {
                     bool hit_backface = dot(ray.d, normal) > 0;
                     if (hit_backface) normal = -normal;
                     ior_ratio = hit_backface ? mparam : 1 / mparam;
@@ -342,9 +392,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     reflect_prob = reflectance(cos_theta, ior_ratio);
                     must_reflect = ior_ratio * sin_theta > 1.0f;  // short-circuit: no uniform is drawn
                 }
-                f3 scatter_dir;
-                bool scattered_ok = true;
-                if (is_diel) {
+                f3 scatter_dir = mk3(0.0f);
+                bool scattered_ok = !path_over;
+                if (path_over) {
+                    // nothing to sample: the path ends here with what it has collected
+                } else if (is_diel) {
                     if (must_reflect || reflect_prob > rng.next()) scatter_dir = reflect(unit_dir, normal);
                     else scatter_dir = refract(unit_dir, normal, ior_ratio);
                 } else {
@@ -356,13 +408,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         scatter_dir = normal + on_unit;
                         scattered_ok = !near_zero(scatter_dir);
                         if (mtype == RT_MAT_LAMBERTIAN_CHECKER) {
-                            const rt_material& mg = p.scene.mats[mat_bits & 0x1fffffffu];
+                            const rt_material& mg = p.scene.mats[mat_bits & RT_MAT_INDEX_MASK];
                             albedo = checker_value(albedo, mk3(mg.albedo2[0], mg.albedo2[1], mg.albedo2[2]), mparam, hit_p);
                         }
                     }
                 }
                 if (!scattered_ok) {
-                    RT_EMIT(0.0f, 0.0f, 0.0f);
+                    RT_EMIT_DARK();
                 } else {
                     atten = atten * albedo;
                     ray.o = hit_p;
@@ -411,6 +463,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     rng_in_unit2(rng, jx, jy);  // Renderer.cu:199
                     ray = camera_sample_ray(p.cam, ndcx + jx * psx, ndcy + jy * psy, rng);
                     atten = mk3(1.0f);
+                    if (EXT) accum_rad = mk3(0.0f);
                     depth = 0;
                     if (p.max_depth == 0u) {
                         RT_EMIT(0.0f, 0.0f, 0.0f);
@@ -437,6 +490,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #undef RT_BEGIN_TRACE
 #undef RT_POP
 #undef RT_EMIT
+#undef RT_EMIT_DARK
 }
 
 // Adds the samples of one pass to each pixel IN SAMPLE ORDER (Renderer.cu:198-204: `radiance += ...`),

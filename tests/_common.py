@@ -57,11 +57,53 @@ def config_cameras(p, which, W, H):
         return p.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
     if which == "book2_moving":   # config 3
         return p.MotionBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.0, 1.0)
+    if which == "cornell_box":    # config 4 (not in the reference): the book's Cornell camera
+        return p.PinholeCamera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, W / H)
     raise ValueError(which)
 
 
 def config_scene(p, which, seed=1984):
-    return getattr(p.Scene, which)() if which == "three_spheres" else getattr(p.Scene, which)(seed)
+    return getattr(p.Scene, which)() if which in ("three_spheres", "cornell_box") else getattr(p.Scene, which)(seed)
+
+
+def random_mixed_scene(p, rng, n_spheres, n_quads, builder, background=None, lights=True):
+    """The same random spheres + quads (+ lights) through the product vocabulary and the oracle's arrays."""
+    s = p.Scene()
+    n_mats = 6
+    mats = np.zeros(n_mats, dtype=O.MAT_DT)
+    for i in range(n_mats):
+        albedo = rng.random(3, dtype=np.float32)
+        mtype = [0, 1, 2, 0, 1, 4][i] if lights else [0, 1, 2, 0, 1, 0][i]
+        if mtype == 4:
+            albedo = (albedo * np.float32(6.0)).astype(np.float32)
+        param = np.float32([0.0, 0.3, 1.5, 0.0, 0.0, 0.0][i])
+        s.add_material(mtype, albedo, float(param))
+        mats[i] = (albedo, param, (0, 0, 0), mtype)
+    prims = np.zeros(n_spheres, dtype=O.PRIM_DT)
+    for i in range(n_spheres):
+        c0 = (rng.random(3, dtype=np.float32) * 10 - 5).astype(np.float32)
+        moving = bool(i % 4 == 0)
+        c1 = (c0 + rng.random(3, dtype=np.float32) * np.float32(0.5)).astype(np.float32) if moving else c0
+        rad = np.float32(0.2 + rng.random() * 0.8)
+        m = int(rng.integers(0, n_mats))
+        (s.MakeMovingSphere(c0, c1, rad, m) if moving else s.MakeSphere(c0, rad, m))
+        prims[i] = (c0, rad, c1, m | (0x80000000 if moving else 0))
+    quads = np.zeros(n_quads, dtype=O.QUAD_DT)
+    for i in range(n_quads):
+        Q = (rng.random(3, dtype=np.float32) * 12 - 6).astype(np.float32)
+        if i % 3 == 0:  # axis-aligned like the Cornell walls (zero-thickness boxes get padded)
+            u = np.float32([rng.random() * 4 + 0.5, 0, 0]); v = np.float32([0, 0, rng.random() * 4 + 0.5])
+        else:
+            u = (rng.standard_normal(3) * 2).astype(np.float32); v = (rng.standard_normal(3) * 2).astype(np.float32)
+        m = int(rng.integers(0, n_mats))
+        s.MakeQuad(Q, u, v, m)
+        quads[i]["Q"], quads[i]["u"], quads[i]["v"], quads[i]["mat"] = Q, u, v, m
+    if background is not None:
+        s.set_background(background)
+    [s.BuildBVH_TopDown, s.BuildBVH_SAH, s.BuildBVH_BottomUp, s.MakeHittableList][builder]()
+    o = O.Scene.from_arrays_ext(prims, quads, mats, builder, 0 if background is None else 1,
+                                (0, 0, 0) if background is None else background)
+    return s, o
 
 
 def oracle_scene(which, seed=1984):

@@ -32,7 +32,9 @@ class World(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("root", C.c_int32), ("n_nodes", C.c_uint32), ("n_prims", C.c_uint32),
                 ("n_materials", C.c_uint32), ("max_stack", C.c_uint32),
                 ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
-                ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p)]
+                ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p),
+                ("quads", C.c_void_p), ("n_quads", C.c_uint32), ("background", C.c_uint32),
+                ("background_color", C.c_float * 3), ("reserved", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -50,6 +52,8 @@ class Counters(C.Structure):
 NODE_DT = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("left", "<i4"), ("right", "<i4")])
 PRIM_DT = np.dtype([("c0", "<f4", 3), ("radius", "<f4"), ("c1", "<f4", 3), ("mat", "<u4")])
 MAT_DT = np.dtype([("albedo", "<f4", 3), ("param", "<f4"), ("albedo2", "<f4", 3), ("type", "<u4")])
+QUAD_DT = np.dtype([("Q", "<f4", 3), ("D", "<f4"), ("u", "<f4", 3), ("mat", "<u4"), ("v", "<f4", 3), ("pad0", "<f4"),
+                    ("normal", "<f4", 3), ("pad1", "<f4"), ("w", "<f4", 3), ("pad2", "<f4")])
 
 _lib = None
 
@@ -102,6 +106,9 @@ def lib():
         getattr(L, name).argtypes = [C.c_uint64]
         getattr(L, name).restype = C.c_void_p
     L.orc_scene_three_spheres.restype = C.c_void_p
+    L.orc_scene_cornell_box.restype = C.c_void_p
+    L.orc_scene_from_arrays_ext.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    L.orc_scene_from_arrays_ext.restype = C.c_void_p
     L.orc_scene_from_arrays.argtypes = [C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
     L.orc_scene_from_arrays.restype = C.c_void_p
     L.orc_scene_world.argtypes = [C.c_void_p, C.POINTER(World)]
@@ -135,6 +142,20 @@ class Scene:
         return cls(lib().orc_scene_three_spheres())
 
     @classmethod
+    def cornell_box(cls):
+        return cls(lib().orc_scene_cornell_box())
+
+    @classmethod
+    def from_arrays_ext(cls, prims, quads, mats, builder=0, background=0, background_color=(0, 0, 0)):
+        prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
+        quads = np.ascontiguousarray(quads, dtype=QUAD_DT)
+        mats = np.ascontiguousarray(mats, dtype=MAT_DT)
+        bg = (C.c_float * 3)(*[float(x) for x in background_color])
+        return cls(lib().orc_scene_from_arrays_ext(len(prims), prims.ctypes.data if len(prims) else None, len(quads),
+                                                   quads.ctypes.data if len(quads) else None, len(mats), mats.ctypes.data,
+                                                   builder, background, bg))
+
+    @classmethod
     def from_arrays(cls, prims, mats, builder=0):
         prims = np.ascontiguousarray(prims, dtype=PRIM_DT)
         mats = np.ascontiguousarray(mats, dtype=MAT_DT)
@@ -153,6 +174,10 @@ class Scene:
     @property
     def prims(self):
         return self._arr(self.world.prims, self.world.n_prims, PRIM_DT)
+
+    @property
+    def quads(self):
+        return self._arr(self.world.quads, self.world.n_quads, QUAD_DT)
 
     @property
     def materials(self):

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import _oracle as O
-from _common import ROOT, as_oracle_world, bits_equal, config_cameras, oracle_scene, pkg
+from _common import ROOT, as_oracle_world, bits_equal, config_cameras, oracle_scene, pkg, random_mixed_scene
 
 
 def test_library_loads_and_exports_every_declared_symbol():
@@ -30,7 +30,7 @@ def test_struct_layouts_match_header_sizes():
     p = pkg()
     assert p.capi.NODE_DT.itemsize == 32 and p.capi.PRIM_DT.itemsize == 32 and p.capi.MAT_DT.itemsize == 32
     assert C.sizeof(p.capi.Camera) == 76
-    assert C.sizeof(p.capi.WorldFlat) == C.sizeof(O.World) == 72
+    assert C.sizeof(p.capi.WorldFlat) == C.sizeof(O.World) == 104
     assert C.sizeof(p.capi.Camera) == C.sizeof(O.Camera)
 
 
@@ -81,6 +81,54 @@ def test_bvh_builders_match_oracle(builder, seed):
     assert pprims.tobytes() == o.prims.tobytes()
     assert pmats.tobytes() == o.materials.tobytes()
     assert bits_equal(np.array(w.bounds_min[:]), np.array(ow.bounds_min[:]))
+
+
+def test_cornell_box_prefab_matches_oracle_bit_for_bit():
+    """BASELINE configs[3] (extension, not in the reference): 18 quads, 4 materials, black background."""
+    p = pkg()
+    s, o = p.Scene.cornell_box(), O.Scene.cornell_box()
+    w, ow = s.getWorldPtr(), o.world
+    for f in ("kind", "root", "n_nodes", "n_prims", "n_materials", "max_stack", "n_quads", "background"):
+        assert getattr(w, f) == getattr(ow, f), f
+    assert (w.n_quads, w.n_prims, w.n_nodes, w.background) == (18, 0, 35, 1)
+    assert bits_equal(np.array(w.background_color[:]), np.array(ow.background_color[:]))
+    nodes, prims, mats = s.arrays()
+    assert nodes.tobytes() == o.nodes.tobytes() and mats.tobytes() == o.materials.tobytes()
+    assert s.quads().tobytes() == o.quads.tobytes()
+    assert [int(m["type"]) for m in mats] == [0, 0, 0, 4]
+
+
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+def test_builders_with_quads_match_oracle(builder):
+    """spheres + quads through every world builder: same tree, same per-kind primitive order, same cached
+    plane quantities as the oracle's restatement of quad::quad / set_bounding_box."""
+    p = pkg()
+    rng = np.random.default_rng(40 + builder)
+    s, o = random_mixed_scene(p, rng, 23, 17, builder, background=(0.1, 0.2, 0.3))
+    nodes, prims, mats = s.arrays()
+    w, ow = s.getWorldPtr(), o.world
+    assert (w.kind, w.root, w.n_nodes, w.max_stack, w.n_prims, w.n_quads, w.background) == \
+           (ow.kind, ow.root, ow.n_nodes, ow.max_stack, ow.n_prims, ow.n_quads, ow.background)
+    assert nodes.tobytes() == o.nodes.tobytes()
+    assert prims.tobytes() == o.prims.tobytes()
+    assert s.quads().tobytes() == o.quads.tobytes()
+    assert mats.tobytes() == o.materials.tobytes()
+    assert bits_equal(np.array(w.bounds_min[:]), np.array(ow.bounds_min[:]))
+    assert bits_equal(np.array(w.bounds_max[:]), np.array(ow.bounds_max[:]))
+
+
+def test_quads_are_refused_where_the_world_cannot_hold_them():
+    p = pkg()
+    s = p.Scene()
+    m = s.Lambertian((0.5, 0.5, 0.5))
+    with pytest.raises(p.capi.RtError):
+        s.MakeQuad((0, 0, 0), (1, 0, 0), (0, 1, 0), 7)        # unknown material
+    a = s.MakeSphere((0, 0, 0), 1.0, m)
+    b = s.MakeSphere((3, 0, 0), 1.0, m)
+    s.MakeQuad((0, 0, 0), (1, 0, 0), (0, 1, 0), m)
+    root = s.bvh_node(p.Scene.prim_ref(a), p.Scene.prim_ref(b))
+    with pytest.raises(p.capi.RtError):
+        s.set_world_node_tree(root)                            # bvh_node trees take spheres only
 
 
 def test_bvh_structure_invariants():
