@@ -100,6 +100,14 @@ public:
     MovingSphere(glm::vec3 c0, glm::vec3 c1, float r) : center0(c0), center1(c1), radius(r) {}
 };
 
+// quad(Q,u,v) of "Ray Tracing: The Next Week" — extension, not in the reference
+class Quad : public Geometry {
+public:
+    glm::vec3 Q, u, v;
+    Quad() {}
+    Quad(glm::vec3 q, glm::vec3 uu, glm::vec3 vv) : Q(q), u(uu), v(vv) {}
+};
+
 // Material (rt_engine/shaders/material.cuh:15-29) as a host descriptor
 class Material {
 public:
@@ -137,6 +145,12 @@ public:
     LambertianTexture(glm::vec3 c1, glm::vec3 c2, float scale) : GeometryDependantMaterial<G>(RT_MAT_LAMBERTIAN_CHECKER, c1, 1.0f / scale, c2) {}
 };
 
+// diffuse_light of "The Next Week" — extension, not in the reference: emits `emit`, never scatters
+template <typename G> class DiffuseLightAbstract : public GeometryDependantMaterial<G> {
+public:
+    explicit DiffuseLightAbstract(glm::vec3 emit) : GeometryDependantMaterial<G>(RT_MAT_DIFFUSE_LIGHT, emit, 0.0f) {}
+};
+
 // newOnDevice<T>(args...) (cuda_utils.cuh:16-23): the reference cudaMallocs one object and runs a <<<1,1>>>
 // placement-new kernel + cudaDeviceSynchronize per call; here it is a host allocation of the descriptor.
 template <typename T, typename... Args> inline T* newOnDevice(const Args&... args) { return new T(args...); }
@@ -146,7 +160,7 @@ template <typename T, typename... Args> inline T* newOnDevice(const Args&... arg
 // ----------------------------------------------------------------------------------------------------
 class Hittable {
 public:
-    enum Kind { SPHERE, MOVING_SPHERE, LIST, NODE, BVH_WORLD };
+    enum Kind { SPHERE, MOVING_SPHERE, QUAD, LIST, NODE, BVH_WORLD };
     virtual ~Hittable() = default;
     virtual Kind kind() const = 0;
 };
@@ -164,11 +178,24 @@ public:
     MovingSphereHittable(const MovingSphere& s, const Material* m) : moving_sphere(s), mat_ptr(m) {}
     Kind kind() const override { return MOVING_SPHERE; }
 };
+class QuadHittable : public Hittable {  // extension
+public:
+    Quad quad;
+    const Material* mat_ptr;
+    QuadHittable(const Quad& q, const Material* m) : quad(q), mat_ptr(m) {}
+    Kind kind() const override { return QUAD; }
+};
+// camera::background of "The Next Week" — extension; unset = the reference's sky gradient (Renderer.cu:150-151)
+struct Background {
+    bool constant = false;
+    glm::vec3 color{0.0f};
+};
 // HittableList(objects, object_count, bounds) — HittableList.cuh:19
 class HittableList : public Hittable {
 public:
     std::vector<const Hittable*> objects;
     aabb bounds;
+    Background background;
     HittableList(const Hittable** objs, int object_count, const aabb& b) : objects(objs, objs + object_count), bounds(b) {}
     Kind kind() const override { return LIST; }
 };
@@ -216,10 +243,19 @@ public:
             float c0[3] = {mh->moving_sphere.center0[0], mh->moving_sphere.center0[1], mh->moving_sphere.center0[2]};
             float c1[3] = {mh->moving_sphere.center1[0], mh->moving_sphere.center1[1], mh->moving_sphere.center1[2]};
             check(rt_scene_add_moving_sphere(s_, c0, c1, mh->moving_sphere.radius, material(mh->mat_ptr), &prim), "rt_scene_add_moving_sphere");
+        } else if (h->kind() == Hittable::QUAD) {
+            auto* qh = static_cast<const QuadHittable*>(h);
+            float Q[3] = {qh->quad.Q[0], qh->quad.Q[1], qh->quad.Q[2]}, u[3] = {qh->quad.u[0], qh->quad.u[1], qh->quad.u[2]};
+            float v[3] = {qh->quad.v[0], qh->quad.v[1], qh->quad.v[2]};
+            check(rt_scene_add_quad(s_, Q, u, v, material(qh->mat_ptr), &prim), "rt_scene_add_quad");
         } else {
-            throw std::runtime_error("only spheres can be leaves of a world (the reference has no other geometry)");
+            throw std::runtime_error("only spheres and quads can be leaves of a world");
         }
         return prim;
+    }
+    void background(const Background& b) {
+        float c[3] = {b.color[0], b.color[1], b.color[2]};
+        check(rt_scene_set_background(s_, b.constant ? 1u : 0u, c), "rt_scene_set_background");
     }
     // child reference of a bvh_node tree: >= 0 node, < 0 primitive
     int32_t tree_ref(const Hittable* h) {
@@ -280,6 +316,35 @@ public:
     aabb getBounds() const { return bounds; }
 };
 
+// QuadHandle — extension in SphereHandle's shape (move-only; owns material + hittable).  The material may be shared
+// between quads (the Cornell walls): pass owns_material = false for all but one handle.
+class QuadHandle {
+    aabb bounds;
+    std::unique_ptr<Material> material_ptr;
+    std::unique_ptr<Hittable> hittable_ptr;
+    QuadHandle() = default;
+
+public:
+    QuadHandle(QuadHandle&&) = default;
+    QuadHandle& operator=(QuadHandle&&) = default;
+    ~QuadHandle() = default;
+    template <typename MatType> static QuadHandle MakeQuad(const Quad& quad, MatType* mat_ptr, bool owns_material = true) {
+        static_assert(GeoAcceptableMat<Quad, MatType>, "material is not declared for Quad");
+        QuadHandle qh;
+        // set_bounding_box of the book: the two diagonals' boxes; the library pads zero-thickness axes when it builds
+        glm::vec3 a = quad.Q, b = quad.Q + quad.u + quad.v, c = quad.Q + quad.u, d = quad.Q + quad.v;
+        auto lo = [](float x, float y) { return y < x ? y : x; };
+        auto hi = [](float x, float y) { return x < y ? y : x; };
+        qh.bounds = aabb(glm::vec3(lo(a[0], b[0]), lo(a[1], b[1]), lo(a[2], b[2])), glm::vec3(hi(a[0], b[0]), hi(a[1], b[1]), hi(a[2], b[2])));
+        qh.bounds += aabb(glm::vec3(lo(c[0], d[0]), lo(c[1], d[1]), lo(c[2], d[2])), glm::vec3(hi(c[0], d[0]), hi(c[1], d[1]), hi(c[2], d[2])));
+        if (owns_material) qh.material_ptr.reset(mat_ptr);
+        qh.hittable_ptr.reset(new QuadHittable(quad, mat_ptr));
+        return qh;
+    }
+    const Hittable* getHittablePtr() const { return hittable_ptr.get(); }
+    aabb getBounds() const { return bounds; }
+};
+
 // ----------------------------------------------------------------------------------------------------
 // BVH_Handle + Factory — rt_engine/geometry/BVH.cuh:42-101
 // ----------------------------------------------------------------------------------------------------
@@ -300,13 +365,16 @@ public:
 class BVH_Handle::Factory {
     std::vector<std::tuple<aabb, const Hittable*>>& arr;
     std::unique_ptr<rt06::SceneBuilder> builder_;
+    Background background_;
     void collect() {
         builder_.reset(new rt06::SceneBuilder());
         for (auto& e : arr) builder_->primitive(std::get<1>(e));
+        builder_->background(background_);
     }
 
 public:
     explicit Factory(std::vector<std::tuple<aabb, const Hittable*>>& a) : arr(a) {}
+    void SetBackground(glm::vec3 color) { background_.constant = true; background_.color = color; }  // extension; call before Build*
     void BuildBVH_TopDown() { collect(); rt06::check(rt_scene_build_bvh_topdown(builder_->get()), "BuildBVH_TopDown"); }  // _build_bvh_rec1
     void BuildBVH_TopDown_SAH() { collect(); rt06::check(rt_scene_build_bvh_sah(builder_->get()), "BuildBVH_TopDown_SAH"); }  // _build_bvh_rec2 (the #else branch, BVH.cu:168-172)
     void BuildBVH_BottomUp() { collect(); rt06::check(rt_scene_build_bvh_bottomup(builder_->get()), "BuildBVH_BottomUp"); }
@@ -373,6 +441,7 @@ class Renderer {
             return;
         case Hittable::LIST:
             for (const Hittable* h : static_cast<const HittableList*>(world)->objects) tmp.primitive(h);
+            tmp.background(static_cast<const HittableList*>(world)->background);
             rt06::check(rt_scene_set_world_list(tmp.get()), "rt_scene_set_world_list");
             break;
         case Hittable::NODE:

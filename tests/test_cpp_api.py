@@ -57,6 +57,46 @@ def test_cpp_renderer_matches_c_abi_path_bit_for_bit():
     assert int(m[1], 16) == fnv1a([img.tobytes()])
 
 
+CORNELL = os.path.join(ROOT, "tests", "cpp", "cornell_app")
+
+
+def test_cpp_quad_vocabulary_builds_the_cornell_box_prefab():
+    """QuadHandle::MakeQuad / DiffuseLightAbstract / Factory::SetBackground (extension) -> the world rt_scene_cornell_box builds."""
+    build_app()
+    out = subprocess.check_output([CORNELL, "flatten"], text=True)
+    m = re.search(r"nodes=(\d+) quads=(\d+) materials=(\d+) root=(-?\d+) max_stack=(\d+) background=(\d+) fnv=([0-9a-f]+)", out)
+    assert m, out
+    p = pkg()
+    s = p.Scene.cornell_box()
+    nodes, _, mats = s.arrays()
+    quads = s.quads()
+    w = s.getWorldPtr()
+    assert tuple(int(m[i]) for i in range(1, 7)) == (w.n_nodes, w.n_quads, w.n_materials, w.root, w.max_stack, w.background)
+    chunks = [nodes.tobytes()]
+    for q in quads:
+        q0 = q.copy()
+        q0["mat"] = 0
+        chunks += [q0.tobytes(), mats[int(q["mat"])].tobytes()]
+    assert int(m[7], 16) == fnv1a(chunks)
+
+
+@pytest.mark.gpu
+def test_cpp_cornell_render_matches_c_abi_path_bit_for_bit():
+    build_app()
+    W, H, spp, depth = 120, 120, 6, 50
+    out = subprocess.check_output([CORNELL, "render", str(W), str(H), str(spp), str(depth)], text=True)
+    m = re.search(r"fnv=([0-9a-f]+)", out)
+    assert m, out
+    p = pkg()
+    s = p.Scene.cornell_box()
+    cam = p.PinholeCamera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, W / H)
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, s.getWorldPtr())
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    r.close()
+    assert int(m[1], 16) == fnv1a([img.tobytes()])
+
+
 def test_header_is_plain_c_and_the_library_links_from_c():
     build_app()
     out = subprocess.check_output([os.path.join(ROOT, "tests", "cpp", "abi_c_check")], text=True)
