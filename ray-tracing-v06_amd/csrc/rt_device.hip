@@ -50,6 +50,18 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// one wide node of the LDS image (layout: rt_stream_kernel.hpp): per child box and axis the triple (min, max, min)
+static void write_wide_node(uint4* blob, uint32_t index, const float lmin[3], const float lmax[3], const float rmin[3],
+                            const float rmax[3], uint32_t lref, uint32_t rref) {
+    uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * RT_NODE_DWORDS;
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    for (int k = 0; k < 3; k++) {
+        d[3 * k + 0] = bits(lmin[k]); d[3 * k + 1] = bits(lmax[k]); d[3 * k + 2] = bits(lmin[k]);
+        d[9 + 3 * k + 0] = bits(rmin[k]); d[9 + 3 * k + 1] = bits(rmax[k]); d[9 + 3 * k + 2] = bits(rmin[k]);
+    }
+    d[RT_NODE_REFS] = (lref & 0xffffu) | (rref << 16);
+}
+
 struct DeviceScene {
     DevBuf nodes, prims, mats, blob, quads;
     bool extended = false;  // quads, an emissive material or a constant background: beyond the reference's feature set
@@ -59,7 +71,7 @@ struct DeviceScene {
     uint32_t true_stack = 0;  // traversal-stack bound computed from the tree itself
     bool regular_boxes = false;  // all box coordinates inside the fast-division class
 
-    // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 64-B wide nodes (both
+    // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 76-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
     int pack(const rt_world_flat* w) {
         has_packed = false;
@@ -82,7 +94,8 @@ struct DeviceScene {
             n_inner = w->n_nodes;
         }
         if (n_inner >= RT_REF_LEAF) return RT_OK;
-        size_t n_vec4 = (size_t)n_inner * RT_NODE_VEC4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials + (size_t)w->n_quads * 5;
+        const uint32_t nodes_vec4 = RT_NODES_VEC4(n_inner);
+        size_t n_vec4 = (size_t)nodes_vec4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials + (size_t)w->n_quads * 5;
         std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));
         if (w->kind == RT_WORLD_BVH) {
             auto ref_of = [&](int32_t node) -> uint32_t {
@@ -94,10 +107,7 @@ struct DeviceScene {
                 const rt_bvh_node& n = w->nodes[i];
                 const rt_bvh_node& l = w->nodes[n.left];
                 const rt_bvh_node& r = w->nodes[n.right];
-                WideNode& o = *reinterpret_cast<WideNode*>(host.data() + (size_t)wide_of[i] * RT_NODE_VEC4);
-                for (int k = 0; k < 3; k++) { o.lmin[k] = l.min[k]; o.lmax[k] = l.max[k]; o.rmin[k] = r.min[k]; o.rmax[k] = r.max[k]; }
-                o.lref = ref_of(n.left); o.rref = ref_of(n.right);
-                o.pad[0] = o.pad[1] = 0;
+                write_wide_node(host.data(), (uint32_t)wide_of[i], l.min, l.max, r.min, r.max, ref_of(n.left), ref_of(n.right));
             }
             packed.root_ref = ref_of(w->root);
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
@@ -111,10 +121,8 @@ struct DeviceScene {
             auto ref_of = [&](int32_t r) -> uint32_t { return r >= 0 ? (uint32_t)r : leaf_ref((uint32_t)(-r - 1)); };
             for (uint32_t i = 0; i < w->n_nodes; i++) {
                 const rt_bvh_node& n = w->nodes[i];
-                WideNode& o = *reinterpret_cast<WideNode*>(host.data() + (size_t)i * RT_NODE_VEC4);
-                for (int k = 0; k < 3; k++) { o.lmin[k] = n.min[k]; o.lmax[k] = n.max[k]; o.rmin[k] = 0.0f; o.rmax[k] = 0.0f; }
-                o.lref = ref_of(n.left); o.rref = ref_of(n.right);
-                o.pad[0] = o.pad[1] = 0;
+                const float zero[3] = {0.0f, 0.0f, 0.0f};
+                write_wide_node(host.data(), i, n.min, n.max, zero, zero, ref_of(n.left), ref_of(n.right));
             }
             packed.root_ref = ref_of(w->root);
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->bounds_min[k]; packed.root_max[k] = w->bounds_max[k]; }
@@ -122,7 +130,7 @@ struct DeviceScene {
             packed.root_ref = RT_REF_LEAF | 0u;
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->bounds_min[k]; packed.root_max[k] = w->bounds_max[k]; }
         }
-        float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)n_inner * RT_NODE_VEC4);
+        float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)nodes_vec4);
         float4* ext = sph + w->n_prims;
         for (uint32_t i = 0; i < w->n_prims; i++) {
             const rt_prim& pr = w->prims[i];
@@ -148,10 +156,10 @@ struct DeviceScene {
         HIP_TRY(blob.upload(host.data(), n_vec4 * sizeof(uint4)));
         packed.blob = blob.as<uint4>();
         packed.blob_vec4 = (uint32_t)n_vec4;
-        packed.off_spheres = n_inner * RT_NODE_VEC4;
-        packed.off_extra = n_inner * RT_NODE_VEC4 + w->n_prims;
-        packed.off_mats = n_inner * RT_NODE_VEC4 + w->n_prims * 2;
-        packed.off_quads = n_inner * RT_NODE_VEC4 + w->n_prims * 2 + w->n_materials;
+        packed.off_spheres = nodes_vec4;
+        packed.off_extra = nodes_vec4 + w->n_prims;
+        packed.off_mats = nodes_vec4 + w->n_prims * 2;
+        packed.off_quads = nodes_vec4 + w->n_prims * 2 + w->n_materials;
         packed.sphere_codes = sphere_codes;
         packed.background = w->background;
         for (int k = 0; k < 3; k++) packed.background_color[k] = w->background_color[k];

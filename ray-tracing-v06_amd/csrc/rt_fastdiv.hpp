@@ -77,6 +77,25 @@ __device__ __forceinline__ bool aabb_intersects_regular(f3 box_min, f3 box_max, 
 }
 
 
+// The same test with the per-axis min/max resolved by the caller: (nx, ny, nz) are the box planes the ray ENTERS
+// through and (fx, fy, fz) the ones it LEAVES through (near = box min where d > 0, box max where d < 0).  RN(n / d)
+// is monotone in n, and b_min <= b_max gives RN(b_min - o) <= RN(b_max - o), so the near quotient IS min(t0, t1)
+// and the far one max(t0, t1) of aabb.cuh:34-39 (up to the sign of a zero) — no v_min/v_max per axis.
+__device__ __forceinline__ bool slab_near_far_regular(float nx, float ny, float nz, float fx, float fy, float fz,
+                                                      const Ray& ray, f3 inv_d, float ray_max_dist, float& tmin_out) {
+    float tnx = fast_div_exact(nx - ray.o.x, ray.d.x, inv_d.x);
+    float tny = fast_div_exact(ny - ray.o.y, ray.d.y, inv_d.y);
+    float tnz = fast_div_exact(nz - ray.o.z, ray.d.z, inv_d.z);
+    float tfx = fast_div_exact(fx - ray.o.x, ray.d.x, inv_d.x);
+    float tfy = fast_div_exact(fy - ray.o.y, ray.d.y, inv_d.y);
+    float tfz = fast_div_exact(fz - ray.o.z, ray.d.z, inv_d.z);
+    float tmin = fmaxf(fmaxf(tnx, tny), tnz);
+    float tmax = fminf(fminf(tfx, tfy), tfz);
+    tmin_out = tmin;
+    return tmin <= tmax && tmin < ray_max_dist && tmax > 0;
+}
+
+
 // ---------------------------------------------------------------------------------------------------
 // Filtered predicates for one inner-node visit (both child boxes) on a regular ray.
 //

@@ -36,26 +36,31 @@
 
 #define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
 #define RT_CHUNK_MAX 1024u       // sample indices a wave pulls per atomic (the host shrinks it for small frames / shards)
-#define RT_NODE_VEC4 4u          // LDS stride of a wide node in 16-B units (padding to 5 spreads bank quads but measured no gain)
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
 #define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
 #define RT_SHADE_MIN 56          // run the shade/regenerate phase once this many lanes wait for it
 #define RT_LEAF_MIN 4            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
-// 64-B wide node: both child boxes + both child references.
+// Wide node, 19 dwords (76 B): both child boxes + both child references.
+//   dwords 3*(3*side + axis) .. +2 = (min, max, min) of that axis of the left (side 0) / right (side 1) child box;
+//   dword 18 = left reference | right reference << 16.
+// The (min, max, min) triple lets a lane read its (near, far) plane pair of an axis as two CONSECUTIVE dwords at
+// offset 0 (direction >= 0: near = min) or 4 bytes (direction < 0: near = max), i.e. the per-axis min/max of the
+// slab test (aabb.cuh:34-39) becomes a per-ray address offset instead of 12 v_min/v_max per visit — on gfx950 min,
+// max, compares and selects issue at half the rate of add/mul/fma (tools/bench_valu_issue.hip).  The odd stride
+// also spreads the rows of different nodes over all LDS banks.
 // A reference is 16 bits wide (an LDS-resident scene has < 2^15 inner nodes and leaf codes):
 //   bit 15 clear: wide-node index;  bit 15 set: leaf, code = ref & 0x7fff = prim * 2 + is_moving.
 // The same encoding travels through the per-lane LDS stack as 16-bit entries.
 #define RT_REF_LEAF 0x8000u
 #define RT_MAT_INDEX_MASK 0x0fffffffu  // matbits: index (28 bits) | moving << 28 | type << 29
-struct WideNode {
-    float lmin[3], lmax[3], rmin[3], rmax[3];
-    uint32_t lref, rref;
-    uint32_t pad[2];
-};
-static_assert(sizeof(WideNode) == 64, "WideNode must be 64 bytes");
+#define RT_NODE_DWORDS 19u
+#define RT_NODE_BYTES (RT_NODE_DWORDS * 4u)
+#define RT_NODE_REFS 18u
+// number of 16-B units the node region of `n` wide nodes occupies in the blob
+#define RT_NODES_VEC4(n) (((n) * RT_NODE_DWORDS + 3u) / 4u)
 
-// LDS image, in 16-B units:  [wide nodes (RT_NODE_VEC4 each) | spheres (c0, r) | extra (c1, matbits) | mats16 (albedo, param) |
+// LDS image, in 16-B units:  [wide nodes (RT_NODE_DWORDS dwords each, region rounded up) | spheres (c0, r) | extra (c1, matbits) | mats16 (albedo, param) |
 //                              quads (5 each: Q,D | u,matbits | v | normal | w)],   matbits = material index | moving << 28 | type << 29
 struct PackedSceneRef {
     const uint4* blob;
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     for (uint32_t i = tid; i < p.scene.blob_vec4; i += BLOCK) lds[i] = p.scene.blob[i];
     __syncthreads();
 
-    const float4* nodes = reinterpret_cast<const float4*>(lds);
+    const char* nodes = reinterpret_cast<const char*>(lds);
     const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
     const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
     const float4* mats16 = reinterpret_cast<const float4*>(lds + p.scene.off_mats);
@@ -152,8 +157,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
-    uint32_t cur = 0;       // node reference being visited (state ST_TRAV)
-    uint32_t sp = 0;
+    // node reference being visited.  INVARIANT: cur < RT_REF_LEAF (an inner node) only while state == ST_TRAV, so the
+    // inner-node phase tests `cur < RT_REF_LEAF` alone.
+    uint32_t cur = RT_REF_LEAF;
+    uint16_t* sp = stack;   // next free entry of this lane's stack (entries are 64 apart)
+    uint32_t kx = 0, ky = 0, kz = 0;  // byte offset (0 / 4) of the (near, far) pair inside an axis triple, per ray
     uint32_t depth = 0;
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
     uint32_t state = ST_NEED;
@@ -174,6 +182,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
             inv_d = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);   \
+            const uint32_t km_ = (regular && !FILTER) ? 4u : 0u;           \
+            kx = (__float_as_uint(ray.d.x) >> 29) & km_;                   \
+            ky = (__float_as_uint(ray.d.y) >> 29) & km_;                   \
+            kz = (__float_as_uint(ray.d.z) >> 29) & km_;                   \
         }                                                                  \
         float d_root_;                                                     \
         bool hit_root_;                                                    \
@@ -182,19 +194,21 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
-            sp = 0;                                                        \
+            sp = stack;                                                    \
             state = ST_TRAV;                                               \
         } else {                                                           \
+            cur = RT_REF_LEAF;                                             \
             state = ST_SHADE;                                              \
         }                                                                  \
     } while (0)
 #define RT_POP()                      \
     do {                              \
-        if (sp == 0) {                \
+        if (sp == stack) {            \
+            cur = RT_REF_LEAF;        \
             state = ST_SHADE;         \
         } else {                      \
-            sp--;                     \
-            cur = stack[sp * 64u];    \
+            sp -= 64;                 \
+            cur = *sp;                \
         }                             \
     } while (0)
 #define RT_EMIT_DARK() RT_EMIT(EXT ? accum_rad.x : 0.0f, EXT ? accum_rad.y : 0.0f, EXT ? accum_rad.z : 0.0f)
@@ -207,80 +221,84 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
     for (;;) {
         // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
-        for (;;) {
-            bool at_inner = (state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u;
-            if (__ballot(at_inner) == 0ull) break;
-            if (at_inner) {
-                const float4* nd = nodes + cur * RT_NODE_VEC4;
-                float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-                const uint32_t left_idx = __float_as_uint(q3.x), right_idx = __float_as_uint(q3.y);
-                if (WORLD == RT_WORLD_NODE_TREE) {
-                    // bvh_node::ClosestIntersection (bvh_node.cuh:19-24): own box, then left subtree, then right
-                    float d_own;
-                    if (aabb_intersects(mk3(q0.x, q0.y, q0.z), mk3(q0.w, q1.x, q1.y), ray, rec_t, d_own)) {
-                        stack[sp * 64u] = (uint16_t)right_idx;
-                        sp++;
-                        cur = left_idx;
+        {
+            bool at_inner = cur < RT_REF_LEAF;
+            uint64_t m_inner = __ballot(at_inner);
+            while (m_inner != 0ull) {
+                if (at_inner) {
+                    const char* nb = nodes + cur * RT_NODE_BYTES;
+                    // (near, far) plane pairs of the three axes; kx/ky/kz are 0 for rays outside the fast class, so
+                    // near == box min and far == box max there
+                    const float* px = reinterpret_cast<const float*>(nb + kx);
+                    const float* py = reinterpret_cast<const float*>(nb + ky);
+                    const float* pz = reinterpret_cast<const float*>(nb + kz);
+                    const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
+                    const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
+                    const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
+                    const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS];
+                    const uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
+                    if (WORLD == RT_WORLD_NODE_TREE) {
+                        // bvh_node::ClosestIntersection (bvh_node.cuh:19-24): own box, then left subtree, then right
+                        float d_own;
+                        if (aabb_intersects(mk3(lnx, lny, lnz), mk3(lfx, lfy, lfz), ray, rec_t, d_own)) {
+                            *sp = (uint16_t)right_idx;
+                            sp += 64;
+                            cur = left_idx;
+                        } else {
+                            RT_POP();
+                        }
                     } else {
-                        RT_POP();
+                        bool hl, hr, swap_lr;
+                        if (EXACT || !regular) {
+                            float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                            hl = aabb_intersects(mk3(lnx, lny, lnz), mk3(lfx, lfy, lfz), ray, rec_t, left_dist);
+                            hr = aabb_intersects(mk3(rnx, rny, rnz), mk3(rfx, rfy, rfz), ray, rec_t, right_dist);
+                            swap_lr = left_dist > right_dist;
+                        } else if (!FILTER) {
+                            float tl, tr;
+                            hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, rec_t, tl);
+                            hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, rec_t, tr);
+                            // left_dist > right_dist with _MISS_DIST for a missed box (BVH.cu:87-90): a hit has tmin < rec_t <= _MISS_DIST
+                            swap_lr = hr && (!hl || tl > tr);
+                        } else {
+                            const f3 lmin = mk3(lnx, lny, lnz), lmax = mk3(lfx, lfy, lfz), rmin = mk3(rnx, rny, rnz), rmax = mk3(rfx, rfy, rfz);
+                            BoxPairDecision dec = box_pair_filtered(lmin, lmax, rmin, rmax, ray, inv_d, rec_t);
+                            hl = dec.hit_left; hr = dec.hit_right; swap_lr = dec.swap;
+                            if (dec.uncertain) {
+                                // a comparison too close to call (~1e-6 of visits): redo the visit with exact quotients.
+                                // The node is re-read (volatile) so that the common path need not keep 12 box
+                                // coordinates alive across the filter.
+                                const volatile float* vn = reinterpret_cast<const volatile float*>(nb);
+                                float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                                hl = aabb_intersects_regular(mk3(vn[0], vn[3], vn[6]), mk3(vn[1], vn[4], vn[7]), ray, inv_d, rec_t, left_dist);
+                                hr = aabb_intersects_regular(mk3(vn[9], vn[12], vn[15]), mk3(vn[10], vn[13], vn[16]), ray, inv_d, rec_t, right_dist);
+                                swap_lr = left_dist > right_dist;
+                            }
+                        }
+                        // "assert that left is closer for next step" (BVH.cu:90-93), then push far / near iff
+                        // dist < rec.distance (BVH.cu:95-96).  A hit box has dist = tmin < rec.distance by aabb.cuh:41 and
+                        // a missed one keeps _MISS_DIST, so the push conditions ARE the hit flags: with both hit the far
+                        // child is pushed and the near one (which would be popped straight away) stays in `cur`; with one
+                        // hit it becomes `cur` (swap_lr is then exactly "the right one"); with none the stack is popped.
+                        if (hl && hr) {
+                            *sp = (uint16_t)(swap_lr ? left_idx : right_idx);
+                            sp += 64;
+                        }
+                        cur = (swap_lr || !hl) ? right_idx : left_idx;
+                        if (!(hl || hr)) RT_POP();
                     }
-                } else {
-                const f3 lmin = mk3(q0.x, q0.y, q0.z), lmax = mk3(q0.w, q1.x, q1.y);
-                const f3 rmin = mk3(q1.z, q1.w, q2.x), rmax = mk3(q2.y, q2.z, q2.w);
-                bool hl, hr, swap_lr;
-                if (EXACT || !regular) {
-                    float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                    hl = aabb_intersects(lmin, lmax, ray, rec_t, left_dist);
-                    hr = aabb_intersects(rmin, rmax, ray, rec_t, right_dist);
-                    swap_lr = left_dist > right_dist;
-                } else if (!FILTER) {
-                    float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                    hl = aabb_intersects_regular(lmin, lmax, ray, inv_d, rec_t, left_dist);
-                    hr = aabb_intersects_regular(rmin, rmax, ray, inv_d, rec_t, right_dist);
-                    swap_lr = left_dist > right_dist;
-                } else {
-                    BoxPairDecision dec = box_pair_filtered(lmin, lmax, rmin, rmax, ray, inv_d, rec_t);
-                    hl = dec.hit_left; hr = dec.hit_right; swap_lr = dec.swap;
-                    if (dec.uncertain) {
-                        // a comparison too close to call (~1e-6 of visits): redo the visit with exact quotients.
-                        // The node is re-read (volatile) so that the common path need not keep 12 box
-                        // coordinates alive across the filter.
-                        const volatile float4* vnd = reinterpret_cast<const volatile float4*>(nd);
-                        float4 r0, r1, r2;
-                        r0.x = vnd[0].x; r0.y = vnd[0].y; r0.z = vnd[0].z; r0.w = vnd[0].w;
-                        r1.x = vnd[1].x; r1.y = vnd[1].y; r1.z = vnd[1].z; r1.w = vnd[1].w;
-                        r2.x = vnd[2].x; r2.y = vnd[2].y; r2.z = vnd[2].z; r2.w = vnd[2].w;
-                        float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                        hl = aabb_intersects_regular(mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), ray, inv_d, rec_t, left_dist);
-                        hr = aabb_intersects_regular(mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), ray, inv_d, rec_t, right_dist);
-                        swap_lr = left_dist > right_dist;
-                    }
                 }
-                // "assert that left is closer for next step" (BVH.cu:90-93), then push far / near iff
-                // dist < rec.distance (BVH.cu:95-96).  A hit box has dist = tmin < rec.distance by aabb.cuh:41 and
-                // a missed one keeps _MISS_DIST, so the push conditions ARE the hit flags.  The near child would
-                // be popped straight away, so it stays in `cur` instead of travelling through the stack.
-                const uint32_t near_idx = swap_lr ? right_idx : left_idx;
-                const uint32_t far_idx = swap_lr ? left_idx : right_idx;
-                const bool hit_near = swap_lr ? hr : hl;
-                const bool hit_far = swap_lr ? hl : hr;
-                if (hit_near && hit_far) {
-                    stack[sp * 64u] = (uint16_t)far_idx;
-                    sp++;
-                }
-                cur = hit_near ? near_idx : far_idx;
-                if (!(hit_near || hit_far)) RT_POP();
-                }
+                at_inner = cur < RT_REF_LEAF;
+                m_inner = __ballot(at_inner);
+                if ((uint32_t)__popcll(m_inner) < p.inner_keep) break;
             }
-            bool still = (state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u;
-            if ((uint32_t)__popcll(__ballot(still)) < p.inner_keep) break;
         }
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
         {
             bool at_leaf = (state == ST_TRAV) && (cur & RT_REF_LEAF) != 0u;
             uint64_t m_leaf = __ballot(at_leaf);
-            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot((state == ST_TRAV) && (cur & RT_REF_LEAF) == 0u) == 0ull)) {
+            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < RT_REF_LEAF) == 0ull)) {
                 if (at_leaf) {
                     uint32_t code = cur & 0x7fffu;   // BVH / tree: prim * 2 + is_moving;  list: prim
                     if (EXT && code >= p.scene.sphere_codes) {
