@@ -112,7 +112,7 @@ struct DeviceScene {
             packed.root_ref = ref_of(w->root);
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
             // rt_fastdiv.hpp condition (a): every box coordinate is 0 or 2^-40 <= |b| < 2^40, boxes not inverted
-            regular_boxes = true;
+            regular_boxes = n_inner < RT_REF_IRR;  // the fast kernel marks references with bit 14
             for (uint32_t i = 0; i < w->n_nodes && regular_boxes; i++)
                 for (int k = 0; k < 3; k++)
                     if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k]) || !(w->nodes[i].min[k] <= w->nodes[i].max[k]))
@@ -383,7 +383,7 @@ struct rt_renderer {
         p.scene = scene.packed;
         p.samples = samples.as<float>();
         p.work_counter = work_counter.as<uint32_t>();
-        p.inner_keep = tune[0]; p.shade_min = tune[1]; p.leaf_min = tune[2];
+        p.inner_keep = tune[0] ? tune[0] : 1u; p.shade_min = tune[1]; p.leaf_min = tune[2];
         uint32_t n_local_pixels = tm.n_local_tiles * RT_TILE * RT_TILE;
         uint32_t grid = n_cus * stream_blocks_per_cu;
         for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp) {

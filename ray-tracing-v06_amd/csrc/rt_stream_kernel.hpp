@@ -53,6 +53,7 @@
 //   bit 15 clear: wide-node index;  bit 15 set: leaf, code = ref & 0x7fff = prim * 2 + is_moving.
 // The same encoding travels through the per-lane LDS stack as 16-bit entries.
 #define RT_REF_LEAF 0x8000u
+#define RT_REF_IRR 0x4000u   // see FAST_BVH in render_kernel_stream
 #define RT_MAT_INDEX_MASK 0x0fffffffu  // matbits: index (28 bits) | moving << 28 | type << 29
 #define RT_NODE_DWORDS 19u
 #define RT_NODE_BYTES (RT_NODE_DWORDS * 4u)
@@ -162,6 +163,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     uint32_t cur = RT_REF_LEAF;
     uint16_t* sp = stack;   // next free entry of this lane's stack (entries are 64 apart)
     uint32_t kx = 0, ky = 0, kz = 0;  // byte offset (0 / 4) of the (near, far) pair inside an axis triple, per ray
+    // FAST_BVH: the default kernel (variant 3).  Inner references of rays outside the fast-division class are marked
+    // with RT_REF_IRR (an LDS-resident tree has < 2^14 inner nodes) so that the hot loop needs no per-lane branch.
+    constexpr bool FAST_BVH = !EXACT && !FILTER && WORLD == RT_WORLD_BVH;
+    bool irr_pending = false;         // wave-uniform: some lane is traversing with a ray outside the class
     uint32_t depth = 0;
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
     uint32_t state = ST_NEED;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
             inv_d = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);   \
-            const uint32_t km_ = (regular && !FILTER) ? 4u : 0u;           \
+            const uint32_t km_ = (regular && FAST_BVH) ? 4u : 0u;          \
             kx = (__float_as_uint(ray.d.x) >> 29) & km_;                   \
             ky = (__float_as_uint(ray.d.y) >> 29) & km_;                   \
             kz = (__float_as_uint(ray.d.z) >> 29) & km_;                   \
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
+            if (FAST_BVH && !regular && cur < RT_REF_LEAF) cur |= RT_REF_IRR; \
             sp = stack;                                                    \
             state = ST_TRAV;                                               \
         } else {                                                           \
@@ -221,14 +227,73 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
     for (;;) {
         // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
-        {
+        if (FAST_BVH) {
+            // Hot loop of the default kernel: lanes whose ray is in the fast-division class (all but a handful).  The
+            // step is straight-line code; lanes outside the class carry RT_REF_IRR in their inner references, so they
+            // fail `cur < RT_REF_IRR` here and are stepped by the verbatim loop below.
+            bool at_inner = cur < RT_REF_IRR;
+            if (__ballot(at_inner) != 0ull) {
+                uint32_t n_inner_lanes;
+                do {
+                    if (at_inner) {
+                        const char* nb = nodes + cur * RT_NODE_BYTES;
+                        const float* px = reinterpret_cast<const float*>(nb + kx);
+                        const float* py = reinterpret_cast<const float*>(nb + ky);
+                        const float* pz = reinterpret_cast<const float*>(nb + kz);
+                        const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
+                        const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
+                        const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
+                        const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS];
+                        const uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
+                        float tl, tr;
+                        const bool hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, rec_t, tl);
+                        const bool hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, rec_t, tr);
+                        // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
+                        // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
+                        // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".
+                        const bool go_right = hr && (!hl || tl > tr);
+                        if (hl && hr) {
+                            *sp = (uint16_t)(go_right ? left_idx : right_idx);
+                            sp += 64;
+                        }
+                        cur = go_right ? right_idx : left_idx;
+                        if (!(hl || hr)) RT_POP();
+                    }
+                    at_inner = cur < RT_REF_IRR;
+                    n_inner_lanes = (uint32_t)__popcll(__ballot(at_inner));
+                } while (n_inner_lanes >= p.inner_keep);   // inner_keep >= 1 (host)
+            }
+            if (irr_pending) {   // wave-uniform, rare: rays with a zero / tiny / huge direction or origin component
+                for (;;) {
+                    const bool at_irr = (cur & (RT_REF_LEAF | RT_REF_IRR)) == RT_REF_IRR;
+                    if (__ballot(at_irr) == 0ull) break;
+                    if (at_irr) {
+                        const float* nf = reinterpret_cast<const float*>(nodes + (cur & (RT_REF_IRR - 1u)) * RT_NODE_BYTES);
+                        uint32_t refs = reinterpret_cast<const uint32_t*>(nf)[RT_NODE_REFS];
+                        uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
+                        if (left_idx < RT_REF_LEAF) left_idx |= RT_REF_IRR;     // inner references stay marked all the way down
+                        if (right_idx < RT_REF_LEAF) right_idx |= RT_REF_IRR;
+                        float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+                        const bool hl = aabb_intersects(mk3(nf[0], nf[3], nf[6]), mk3(nf[1], nf[4], nf[7]), ray, rec_t, left_dist);
+                        const bool hr = aabb_intersects(mk3(nf[9], nf[12], nf[15]), mk3(nf[10], nf[13], nf[16]), ray, rec_t, right_dist);
+                        const bool swap_lr = left_dist > right_dist;
+                        if (hl && hr) {
+                            *sp = (uint16_t)(swap_lr ? left_idx : right_idx);
+                            sp += 64;
+                        }
+                        cur = (swap_lr || !hl) ? right_idx : left_idx;
+                        if (!(hl || hr)) RT_POP();
+                    }
+                }
+                irr_pending = __ballot(!regular && state == ST_TRAV) != 0ull;
+            }
+        } else {
             bool at_inner = cur < RT_REF_LEAF;
             uint64_t m_inner = __ballot(at_inner);
             while (m_inner != 0ull) {
                 if (at_inner) {
                     const char* nb = nodes + cur * RT_NODE_BYTES;
-                    // (near, far) plane pairs of the three axes; kx/ky/kz are 0 for rays outside the fast class, so
-                    // near == box min and far == box max there
+                    // (near, far) plane pairs of the three axes; kx/ky/kz are 0 in these kernels: near == box min, far == box max
                     const float* px = reinterpret_cast<const float*>(nb + kx);
                     const float* py = reinterpret_cast<const float*>(nb + ky);
                     const float* pz = reinterpret_cast<const float*>(nb + kz);
@@ -248,20 +313,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                             RT_POP();
                         }
                     } else {
+                        const f3 lmin = mk3(lnx, lny, lnz), lmax = mk3(lfx, lfy, lfz), rmin = mk3(rnx, rny, rnz), rmax = mk3(rfx, rfy, rfz);
                         bool hl, hr, swap_lr;
                         if (EXACT || !regular) {
                             float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                            hl = aabb_intersects(mk3(lnx, lny, lnz), mk3(lfx, lfy, lfz), ray, rec_t, left_dist);
-                            hr = aabb_intersects(mk3(rnx, rny, rnz), mk3(rfx, rfy, rfz), ray, rec_t, right_dist);
+                            hl = aabb_intersects(lmin, lmax, ray, rec_t, left_dist);
+                            hr = aabb_intersects(rmin, rmax, ray, rec_t, right_dist);
                             swap_lr = left_dist > right_dist;
-                        } else if (!FILTER) {
-                            float tl, tr;
-                            hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, rec_t, tl);
-                            hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, rec_t, tr);
-                            // left_dist > right_dist with _MISS_DIST for a missed box (BVH.cu:87-90): a hit has tmin < rec_t <= _MISS_DIST
-                            swap_lr = hr && (!hl || tl > tr);
                         } else {
-                            const f3 lmin = mk3(lnx, lny, lnz), lmax = mk3(lfx, lfy, lfz), rmin = mk3(rnx, rny, rnz), rmax = mk3(rfx, rfy, rfz);
                             BoxPairDecision dec = box_pair_filtered(lmin, lmax, rmin, rmax, ray, inv_d, rec_t);
                             hl = dec.hit_left; hr = dec.hit_right; swap_lr = dec.swap;
                             if (dec.uncertain) {
@@ -502,6 +561,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             }
         }
         if (start_trace) RT_BEGIN_TRACE();
+        if (FAST_BVH && __ballot(start_trace && !regular) != 0ull) irr_pending = true;
         if (pool_dry && state == ST_NEED) state = ST_OFF;
         if (__ballot(state != ST_OFF) == 0ull) break;
     }

@@ -607,6 +607,24 @@ def test_irregular_box_coordinates_fall_back_to_the_verbatim_kernel(p):
     assert bits_equal(img, ref), mismatch_report(img, ref)
 
 
+def test_rays_outside_the_fast_division_class_take_the_verbatim_loop(p):
+    """A camera origin component of 1e-30 (non-zero, below 2^-60) puts EVERY primary ray outside the fast-division
+    class of rt_fastdiv.hpp while the scattered rays are inside it: the default kernel must step the former through
+    its verbatim loop (marked inner references) and the latter through the fast one, in the same wave."""
+    s = config_scene(p, "book1_final")
+    W, H, spp = 160, 100, 8
+    cam = p.DefocusBlurCamera((1e-30, 2.0, 9.0), (0, 0.5, 0), (0, 1, 0), 35.0, W / H, 0.0, 9.0)
+    img, ref = _render_both(p, s, cam, W, H, spp)
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    cam0 = p.DefocusBlurCamera((0.0, 2.0, 9.0), (0, 0.5, 0), (0, 1, 0), 35.0, W / H, 0.0, 9.0)  # zero IS in the class
+    img0, ref0 = _render_both(p, s, cam0, W, H, spp)
+    assert bits_equal(img0, ref0), mismatch_report(img0, ref0)
+    # axis-parallel view direction: primary rays with exactly zero direction components (1/d = inf)
+    cam1 = p.PinholeCamera((0, 1, 12), (0, 1, 0), (0, 1, 0), 40.0, W / H)
+    img1, ref1 = _render_both(p, s, cam1, W, H, 1)
+    assert bits_equal(img1, ref1), mismatch_report(img1, ref1)
+
+
 @pytest.mark.parametrize("seed", list(range(12)))
 def test_random_scenes_cameras_and_builders_render_bit_exact(p, seed):
     """Differential fuzz: random sphere soups (static / moving, all four materials, overlapping and nested spheres,

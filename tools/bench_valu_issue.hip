@@ -165,6 +165,37 @@ __global__ __launch_bounds__(768) void k_ds_read_b128(float* out, float a, float
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
+
+// scalar ALU: is it hidden behind the vector issue or a second budget?  (a) SALU alone, (b) 8 v_fma + N s_and_b64 interleaved
+__global__ __launch_bounds__(768) void k_salu(float* out, float a, float b) {
+    unsigned long long m0 = __builtin_amdgcn_readfirstlane(threadIdx.x) + 1, m1 = m0 * 3, m2 = m0 * 5, m3 = m0 * 7;
+    unsigned long long k = 0x00ff00ff00ff00ffull | (unsigned long long)__builtin_amdgcn_readfirstlane(__float_as_uint(a));
+    for (int i = 0; i < N_ITER; i++) {
+        asm volatile("s_and_b64 %0, %0, %4\n s_or_b64 %1, %1, %4\n s_xor_b64 %2, %2, %4\n s_andn2_b64 %3, %3, %4\n"
+                     "s_or_b64 %0, %0, %4\n s_and_b64 %1, %1, %4\n s_andn2_b64 %2, %2, %4\n s_xor_b64 %3, %3, %4\n"
+                     : "+s"(m0), "+s"(m1), "+s"(m2), "+s"(m3) : "s"(k) : "scc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)((m0 ^ m1 ^ m2 ^ m3) & 0xff);
+}
+#define DEF_MIX(NAME, SALU_TEXT)                                                                                    \
+    __global__ __launch_bounds__(768) void NAME(float* out, float a, float b) {                                     \
+        float x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; \
+        unsigned long long m0 = __builtin_amdgcn_readfirstlane(threadIdx.x) + 1, m1 = m0 * 3;                       \
+        unsigned long long k = 0x00ff00ff00ff00ffull | (unsigned long long)__builtin_amdgcn_readfirstlane(__float_as_uint(a)); \
+        for (int i = 0; i < N_ITER; i++) {                                                                          \
+            asm volatile("v_fma_f32 %0, %0, %10, %11\n" SALU_TEXT "v_fma_f32 %1, %1, %10, %11\n" SALU_TEXT "v_fma_f32 %2, %2, %10, %11\n" SALU_TEXT \
+                         "v_fma_f32 %3, %3, %10, %11\n" SALU_TEXT "v_fma_f32 %4, %4, %10, %11\n" SALU_TEXT "v_fma_f32 %5, %5, %10, %11\n" SALU_TEXT \
+                         "v_fma_f32 %6, %6, %10, %11\n" SALU_TEXT "v_fma_f32 %7, %7, %10, %11\n" SALU_TEXT                 \
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+s"(m0), "+s"(m1) \
+                         : "v"(a), "v"(b), "s"(k) : "scc");                                                         \
+        }                                                                                                           \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + (float)((m0 ^ m1) & 0xff); \
+    }
+DEF_MIX(k_mix_8v_4s, "s_and_b64 %8, %8, %12\n")
+
+DEF_MIX(k_mix_8v_8s, "s_and_b64 %8, %8, %12\n s_or_b64 %9, %9, %12\n")
+DEF_MIX(k_mix_8v_0s, "")
+
 static int g_clock_khz = 2400000;
 template <typename K> static void run(const char* name, K kern, float* out, int blocks_per_cu, int instr_per_iter = 8) {
     hipEvent_t e0, e1;
@@ -234,6 +265,10 @@ int main() {
     run("v_cndmask_b32", k_cndmask, out, b);
     run("v_mad_u64_u32", k_mad64, out, b);
     run("ds_read_b128 x2+", k_ds_read_b128, out, b, 2);
+    run("SALU b64 logic x8", k_salu, out, b);
+    run("8 v_fma (+0 salu)", k_mix_8v_0s, out, b);
+    run("8 v_fma + 8 salu", k_mix_8v_4s, out, b);
+    run("8 v_fma + 16 salu", k_mix_8v_8s, out, b);
     run("v_pk_mul_f32", k_pk_mul, out, b);
     run("v_pk_fma_f32", k_pk_fma, out, b);
     return 0;
