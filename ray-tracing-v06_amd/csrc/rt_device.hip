@@ -397,8 +397,27 @@ struct rt_renderer {
             if (const char* env = std::getenv("RT06_CHUNK")) { int v = std::atoi(env); if (v >= 64 && v <= 1024) chunk = (uint32_t)v & ~63u; }
             p.chunk = chunk;
             HIP_TRY(hipMemsetAsync(work_counter.p, 0, 4, st));
+#ifdef RT_PHASE_TIMERS
+            DevBuf phase_acc;
+            HIP_TRY(phase_acc.alloc(32 * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(phase_acc.p, 0, 32 * sizeof(unsigned long long), st));
+            p.phase_acc = phase_acc.as<unsigned long long>();
+#endif
             void* args[] = {&p};
             HIP_TRY(hipLaunchKernel(stream_kernel_ptr(), dim3(grid), dim3(stream_block), args, stream_lds_bytes, st));
+#ifdef RT_PHASE_TIMERS
+            {
+                unsigned long long h[32];
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(hipMemcpy(h, phase_acc.p, sizeof(h), hipMemcpyDeviceToHost));
+                static const char* names[16] = {"hot inner loop", "irregular loop", "leaf phase", "shade (tail)", "regenerate", "begin trace", "(inner steps)", "loop top",
+                                                "schedule check", "shade: miss/sky + hit common", "shade: dielectric prep", "shade: dielectric dir", "shade: on-unit-sphere loop", "shade: metal/lambert/checker", "-", "-"};
+                unsigned long long tot = 0;
+                for (int i = 0; i < 16; i++) tot += h[i];
+                for (int i = 0; i < 16; i++)
+                    fprintf(stderr, "[phase] %-16s %6.2f %% of wave time, %12llu visits, %8.1f cycles per visit\n", names[i], 100.0 * h[i] / (double)tot, h[16 + i], h[16 + i] ? (double)h[i] / h[16 + i] : 0.0);
+            }
+#endif
             uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
             resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
             HIP_TRY(hipGetLastError());

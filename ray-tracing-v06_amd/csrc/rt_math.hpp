@@ -145,11 +145,14 @@ RT_HD void rng_in_unit2(Rng& g, float& ox, float& oy) {
 }
 // glm::cuRandomOnUnit<3>, utils:92-98
 RT_HD f3 rng_on_unit3(Rng& g) {
+    // the normalisation (sqrt + division) sits AFTER the rejection loop: inside it a wave would execute it once per
+    // iteration in which any lane accepts, i.e. ~6 times per call instead of once
+    f3 v;
     for (;;) {
-        f3 v;
         v.x = g.next() * 2.0f - 1.0f;
         v.y = g.next() * 2.0f - 1.0f;
         v.z = g.next() * 2.0f - 1.0f;
-        if (!near_zero(v) && length2(v) < 1.0f) return normalize(v);
+        if (!near_zero(v) && length2(v) < 1.0f) break;
     }
+    return normalize(v);
 }

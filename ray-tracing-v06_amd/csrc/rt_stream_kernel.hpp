@@ -93,6 +93,9 @@ struct StreamParams {
     uint32_t chunk;          // sample indices per work-queue fetch
     float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
     uint32_t* work_counter;
+#ifdef RT_PHASE_TIMERS
+    unsigned long long* phase_acc;  // development build only: [0..15] cycles per phase, [16..31] visits (summed over waves)
+#endif
 };
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
@@ -225,7 +228,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         state = ST_NEED;                                      \
     } while (0)
 
+#ifdef RT_PHASE_TIMERS
+    unsigned long long pt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last_ = __builtin_readcyclecounter();
+    uint32_t pc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_PT(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pt_last_; pt_last_ = n_; pc_[i]++; } while (0)
+#else
+#define RT_PT(i)
+#endif
     for (;;) {
+        RT_PT(7);
         // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
         if (FAST_BVH) {
             // Hot loop of the default kernel: lanes whose ray is in the fast-division class (all but a handful).  The
@@ -261,8 +272,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     }
                     at_inner = cur < RT_REF_IRR;
                     n_inner_lanes = (uint32_t)__popcll(__ballot(at_inner));
+#ifdef RT_PHASE_TIMERS
+                    pc_[6]++;
+#endif
                 } while (n_inner_lanes >= p.inner_keep);   // inner_keep >= 1 (host)
             }
+            RT_PT(0);
             if (irr_pending) {   // wave-uniform, rare: rays with a zero / tiny / huge direction or origin component
                 for (;;) {
                     const bool at_irr = (cur & (RT_REF_LEAF | RT_REF_IRR)) == RT_REF_IRR;
@@ -287,6 +302,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 }
                 irr_pending = __ballot(!regular && state == ST_TRAV) != 0ull;
             }
+            RT_PT(1);
         } else {
             bool at_inner = cur < RT_REF_LEAF;
             uint64_t m_inner = __ballot(at_inner);
@@ -401,12 +417,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             }
         }
 
+        RT_PT(2);
         // ================= phase 3: shade finished traces, regenerate finished paths ==================
         uint64_t m_wait = __ballot(state == ST_SHADE || state == ST_NEED);
         uint64_t m_trav = __ballot(state == ST_TRAV);
         if ((uint32_t)__popcll(m_wait) < p.shade_min && m_trav != 0ull) continue;
 
         bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
+        RT_PT(8);
         if (state == ST_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
             if (rec_code < 0) {
                 f3 sky;
@@ -453,6 +471,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     if (mtype == RT_MAT_DIFFUSE_LIGHT) { accum_rad = accum_rad + atten * albedo; path_over = true; }
                     if (depth + 1u >= p.max_depth) path_over = true;
                 }
+                RT_PT(9);
                 // ---- Scatter (cu_materials.cuh:52-64 / 77-95 / 115-143 / 27-40); per-lane arithmetic is
                 // ---- material_scatter()'s, expression by expression.
                 const bool is_diel = (mtype == RT_MAT_DIELECTRIC);
@@ -469,6 +488,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     reflect_prob = reflectance(cos_theta, ior_ratio);
                     must_reflect = ior_ratio * sin_theta > 1.0f;  // short-circuit: no uniform is drawn
                 }
+                RT_PT(10);
                 f3 scatter_dir = mk3(0.0f);
                 bool scattered_ok = !path_over;
                 if (path_over) {
@@ -477,7 +497,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     if (must_reflect || reflect_prob > rng.next()) scatter_dir = reflect(unit_dir, normal);
                     else scatter_dir = refract(unit_dir, normal, ior_ratio);
                 } else {
+                    RT_PT(11);
                     f3 on_unit = rng_on_unit3(rng);
+                    RT_PT(12);
                     if (mtype == RT_MAT_METAL) {
                         scatter_dir = reflect(ray.d, normal) + on_unit * mparam;
                         scattered_ok = !(dot(scatter_dir, normal) < 0 || near_zero(scatter_dir));
@@ -490,6 +512,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         }
                     }
                 }
+                RT_PT(13);
                 if (!scattered_ok) {
                     RT_EMIT_DARK();
                 } else {
@@ -503,6 +526,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             }
         }
 
+        RT_PT(3);
         // ---- hand new samples to the lanes that need one (wave-uniform loop) -------------------------
         for (;;) {
             uint64_t m_need = __ballot(state == ST_NEED);
@@ -560,11 +584,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 b_ok = block_origin(p.tm, pool_blk + 1u, bx0, by0);
             }
         }
+        RT_PT(4);
         if (start_trace) RT_BEGIN_TRACE();
         if (FAST_BVH && __ballot(start_trace && !regular) != 0ull) irr_pending = true;
         if (pool_dry && state == ST_NEED) state = ST_OFF;
+        RT_PT(5);
         if (__ballot(state != ST_OFF) == 0ull) break;
     }
+#ifdef RT_PHASE_TIMERS
+    if (lane == 0)
+        for (int i = 0; i < 16; i++) { atomicAdd(p.phase_acc + i, pt_[i]); atomicAdd(p.phase_acc + 16 + i, (unsigned long long)pc_[i]); }
+#endif
+#undef RT_PT
 #undef RT_BEGIN_TRACE
 #undef RT_POP
 #undef RT_EMIT
