@@ -111,7 +111,19 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
     return gt < tm.n_tiles;
 }
 
-enum : uint32_t { ST_NEED = 0, ST_TRAV = 1, ST_SHADE = 2, ST_OFF = 3 };
+// A lane's status lives in `cur` alone (compares and selects are half-rate on gfx950; one register, one compare):
+//   cur <  RT_REF_IRR              at an inner node, ray in the fast-division class            } tracing
+//   cur <  RT_REF_LEAF             at an inner node (marked RT_REF_IRR: ray outside the class) }  (RT_CUR_TRACING(cur))
+//   cur <  RT_CUR_SHADE            at a leaf: RT_REF_LEAF | code                               }
+//   cur == RT_CUR_SHADE            trace finished, waiting for the shade phase
+//   cur == RT_CUR_NEED             path finished, waiting for a new sample
+//   cur == RT_CUR_OFF              no samples left
+//   cur == RT_CUR_START            got a new ray in this round; its trace begins at the end of the round
+#define RT_CUR_SHADE 0x10000u
+#define RT_CUR_NEED 0x20000u
+#define RT_CUR_OFF 0x30000u
+#define RT_CUR_START 0x40000u
+#define RT_CUR_TRACING(c) ((c) < RT_CUR_SHADE)
 
 // EXACT = true : box tests use aabb_intersects() verbatim (IEEE division, GLM min/max).
 // EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
@@ -161,9 +173,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
-    // node reference being visited.  INVARIANT: cur < RT_REF_LEAF (an inner node) only while state == ST_TRAV, so the
-    // inner-node phase tests `cur < RT_REF_LEAF` alone.
-    uint32_t cur = RT_REF_LEAF;
+    uint32_t cur = RT_CUR_NEED;   // node reference being visited, or the lane's status (see RT_CUR_*)
     uint16_t* sp = stack;   // next free entry of this lane's stack (entries are 64 apart)
     uint32_t kx = 0, ky = 0, kz = 0;  // byte offset (0 / 4) of the (near, far) pair inside an axis triple, per ray
     // FAST_BVH: the default kernel (variant 3).  Inner references of rays outside the fast-division class are marked
@@ -172,7 +182,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     bool irr_pending = false;         // wave-uniform: some lane is traversing with a ray outside the class
     uint32_t depth = 0;
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
-    uint32_t state = ST_NEED;
 
     // ---- wave-uniform work pool: [pool_next, pool_end) + the tile origins of its current block(s) -----
     uint32_t pool_next = 0, pool_end = 0;
@@ -204,17 +213,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             cur = p.scene.root_ref;                                        \
             if (FAST_BVH && !regular && cur < RT_REF_LEAF) cur |= RT_REF_IRR; \
             sp = stack;                                                    \
-            state = ST_TRAV;                                               \
         } else {                                                           \
-            cur = RT_REF_LEAF;                                             \
-            state = ST_SHADE;                                              \
+            cur = RT_CUR_SHADE;                                            \
         }                                                                  \
     } while (0)
 #define RT_POP()                      \
     do {                              \
         if (sp == stack) {            \
-            cur = RT_REF_LEAF;        \
-            state = ST_SHADE;         \
+            cur = RT_CUR_SHADE;       \
         } else {                      \
             sp -= 64;                 \
             cur = *sp;                \
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     do {                                                      \
         float* o_ = p.samples + (size_t)out_idx * 3u;         \
         o_[0] = (rx); o_[1] = (ry); o_[2] = (rz);             \
-        state = ST_NEED;                                      \
+        cur = RT_CUR_NEED;                                    \
     } while (0)
 
 #ifdef RT_PHASE_TIMERS
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         if (!(hl || hr)) RT_POP();
                     }
                 }
-                irr_pending = __ballot(!regular && state == ST_TRAV) != 0ull;
+                irr_pending = __ballot(!regular && RT_CUR_TRACING(cur)) != 0ull;
             }
             RT_PT(1);
         } else {
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
         {
-            bool at_leaf = (state == ST_TRAV) && (cur & RT_REF_LEAF) != 0u;
+            bool at_leaf = (cur - RT_REF_LEAF) < (RT_CUR_SHADE - RT_REF_LEAF);
             uint64_t m_leaf = __ballot(at_leaf);
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < RT_REF_LEAF) == 0ull)) {
                 if (at_leaf) {
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     }
                     if (WORLD == RT_WORLD_LIST) {  // HittableList.cuh:26-30: every object, in order
                         if (prim + 1u < p.scene.n_prims) cur = RT_REF_LEAF | (prim + 1u);
-                        else state = ST_SHADE;
+                        else cur = RT_CUR_SHADE;
                     } else {
                         RT_POP();
                     }
@@ -419,13 +425,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
         RT_PT(2);
         // ================= phase 3: shade finished traces, regenerate finished paths ==================
-        uint64_t m_wait = __ballot(state == ST_SHADE || state == ST_NEED);
-        uint64_t m_trav = __ballot(state == ST_TRAV);
-        if ((uint32_t)__popcll(m_wait) < p.shade_min && m_trav != 0ull) continue;
+        // lanes that are not tracing wait for this phase (switched-off lanes count as waiting: near the end of the
+        // pass that only makes the phase run a little earlier)
+        uint64_t m_trav = __ballot(RT_CUR_TRACING(cur));
+        if (64u - (uint32_t)__popcll(m_trav) < p.shade_min && m_trav != 0ull) continue;
 
         bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
         RT_PT(8);
-        if (state == ST_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
+        if (cur == RT_CUR_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
             if (rec_code < 0) {
                 f3 sky;
                 if (EXT && p.scene.background == 1u) {
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         RT_PT(3);
         // ---- hand new samples to the lanes that need one (wave-uniform loop) -------------------------
         for (;;) {
-            uint64_t m_need = __ballot(state == ST_NEED);
+            uint64_t m_need = __ballot(cur == RT_CUR_NEED);
             if (m_need == 0ull) break;
             if (pool_next == pool_end) {
                 if (pool_dry) break;
@@ -546,7 +553,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             }
             uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(m_need));
             uint32_t rank = lane_rank(m_need);
-            if (state == ST_NEED && rank < take) {
+            if (cur == RT_CUR_NEED && rank < take) {
                 // sample index n -> (64-pixel block, sample, pixel in block): n = (blk * pass_spp + s) * 64 + pix
                 uint32_t rem = pool_rem + rank;
                 bool second = rem >= spb;  // rank < 64 <= spb: at most one block boundary
@@ -570,7 +577,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         RT_EMIT(0.0f, 0.0f, 0.0f);
                     } else {
                         start_trace = true;
-                        state = ST_TRAV;  // leaves ST_NEED now (so the loop does not hand it another sample); set for real below
+                        cur = RT_CUR_START;  // no longer RT_CUR_NEED, so the loop does not hand it another sample
                     }
                 }
                 // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
@@ -587,9 +594,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         RT_PT(4);
         if (start_trace) RT_BEGIN_TRACE();
         if (FAST_BVH && __ballot(start_trace && !regular) != 0ull) irr_pending = true;
-        if (pool_dry && state == ST_NEED) state = ST_OFF;
+        if (pool_dry && cur == RT_CUR_NEED) cur = RT_CUR_OFF;
         RT_PT(5);
-        if (__ballot(state != ST_OFF) == 0ull) break;
+        if (__ballot(cur != RT_CUR_OFF) == 0ull) break;
     }
 #ifdef RT_PHASE_TIMERS
     if (lane == 0)
