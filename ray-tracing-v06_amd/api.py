@@ -320,6 +320,13 @@ def selftest_fastdiv(first_den, n_den, num_exp=0, den_exp=0, device=0):
     return bad.value, ex
 
 
+def selftest_fastrcp(device=0):
+    """rt_selftest_fastrcp: (values checked, mismatches, example bits)."""
+    n, bad, ex = C.c_uint64(), C.c_uint64(), C.c_uint32()
+    check(lib().rt_selftest_fastrcp(device, C.byref(n), C.byref(bad), C.byref(ex)))
+    return n.value, bad.value, ex.value
+
+
 def probe_boxpair_filtered(boxes, rays, max_dist, device=0):
     n = len(boxes)
     out = np.zeros((n, 8), np.int32)

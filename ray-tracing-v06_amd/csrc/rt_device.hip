@@ -789,7 +789,7 @@ __global__ void probe_aabb_regular_kernel(size_t n, const float* boxes, const fl
     float d = 0.0f;
     bool h = false;
     if (reg) {
-        f3 inv_d = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+        f3 inv_d = mk3(rcp_exact_regular(r.d.x), rcp_exact_regular(r.d.y), rcp_exact_regular(r.d.z));  // as the render kernel does
         h = aabb_intersects_regular(bmin, bmax, r, inv_d, maxd[i], d);
     }
     hit[i] = h ? 1 : 0;
@@ -812,6 +812,42 @@ extern "C" int rt_probe_aabb_regular(int device, size_t n, const float* boxes, c
 }
 
 // one block per divisor significand; its 256 threads sweep all 2^23 numerator significands
+__global__ __launch_bounds__(256) void selftest_fastrcp_kernel(unsigned long long* counts, uint32_t* example) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long n = 0, bad = 0;
+    for (uint64_t u = i; u < (1ull << 32); u += stride) {
+        const uint32_t bits = (uint32_t)u;
+        const uint32_t e = (bits >> 23) & 0xffu;
+        if (e < 127u - 40u || e > 127u + 39u) continue;
+        const float x = __uint_as_float(bits);
+        n++;
+        if (__float_as_uint(rcp_exact_regular(x)) != __float_as_uint(1.0f / x)) { bad++; *example = bits; }
+    }
+    atomicAdd(counts + 0, n);
+    atomicAdd(counts + 1, bad);
+}
+
+extern "C" int rt_selftest_fastrcp(int device, uint64_t* checked, uint64_t* mismatches, uint32_t* example) {
+    if (!checked || !mismatches || !example) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastrcp: null argument");
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf counts, ex;
+    HIP_TRY(counts.alloc(16));
+    HIP_TRY(ex.alloc(4));
+    HIP_TRY(hipMemset(counts.p, 0, 16));
+    HIP_TRY(hipMemset(ex.p, 0, 4));
+    selftest_fastrcp_kernel<<<8192, 256>>>(counts.as<unsigned long long>(), ex.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, counts.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(example, ex.p, 4, hipMemcpyDeviceToHost));
+    *checked = h[0];
+    *mismatches = h[1];
+    return RT_OK;
+}
+
 __global__ __launch_bounds__(256) void selftest_fastdiv_kernel(uint32_t first_den, uint32_t num_exp_bits, uint32_t den_exp_bits,
                                                                unsigned long long* mismatches, uint32_t* example) {
     uint32_t md = first_den + blockIdx.x;

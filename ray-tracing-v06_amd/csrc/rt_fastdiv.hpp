@@ -32,6 +32,15 @@ __device__ __forceinline__ float fast_div_exact(float n, float d, float r) {
     return __builtin_fmaf(e1, r, q1);
 }
 
+// RN(1 / x) for 2^-40 <= |x| < 2^40: the hardware reciprocal approximation (1 ulp) plus ONE Newton step is the correctly
+// rounded quotient for every such x — checked exhaustively over all 1,342,177,280 of them against the IEEE division by
+// rt_selftest_fastrcp, run by the GPU tests (0 mismatches).  3 instructions instead of the ~11 of a true division, three times per ray.
+__device__ __forceinline__ float rcp_exact_regular(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+
 RT_HD bool coord_is_regular(float b) {  // b == 0 or 2^-40 <= |b| < 2^40
     uint32_t e;
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         rec_code = -1;                                                     \
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
-            inv_d = mk3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);   \
+            inv_d = mk3(rcp_exact_regular(ray.d.x), rcp_exact_regular(ray.d.y), rcp_exact_regular(ray.d.z)); /* used by regular rays only */ \
             const uint32_t km_ = (regular && FAST_BVH) ? 4u : 0u;          \
             kx = (__float_as_uint(ray.d.x) >> 29) & km_;                   \
             ky = (__float_as_uint(ray.d.y) >> 29) & km_;                   \

@@ -454,6 +454,13 @@ def test_fastdiv_matches_ieee_division(p):
     assert total == 64 << 23
 
 
+def test_fast_reciprocal_is_the_ieee_reciprocal_for_every_value_of_the_class(p):
+    """RN(1/d) of a regular ray is hardware rcp + one Newton step; exhaustive over all fp32 with 2^-40 <= |x| < 2^40."""
+    n, bad, ex = p.api.selftest_fastrcp()
+    assert n == 2 * 80 * (1 << 23)
+    assert bad == 0, f"{bad} mismatches, e.g. x={ex:#x}"
+
+
 def test_box_test_with_fast_division_makes_identical_decisions(p):
     """aabb_intersects_regular vs aabb::intersects on regular rays: same hit flag and same dist."""
     rng = np.random.default_rng(22)
