@@ -313,6 +313,10 @@ int rt_probe_boxpair_filtered(int device, size_t n, const float* boxes, const fl
 int rt_selftest_fastdiv(int device, uint32_t first_den, uint32_t n_den, int32_t num_exp, int32_t den_exp,
                         uint64_t* mismatches, uint32_t example[2]);
 
+/* The same sweep for the 4-instruction quotient from a two-word reciprocal (fast_div_exact4, the one the default
+ * kernel uses).                                                                                             */
+int rt_selftest_fastdiv4(int device, uint32_t first_den, uint32_t n_den, int32_t num_exp, int32_t den_exp,
+                         uint64_t* mismatches, uint32_t example[2]);
 /* Exhaustive self-test of the 3-instruction reciprocal used for RN(1/d) of rays in the fast-division class: every fp32
  * x with 2^-40 <= |x| < 2^40 (1,342,177,280 values) against the IEEE division 1.0f / x, bit for bit.            */
 int rt_selftest_fastrcp(int device, uint64_t* checked, uint64_t* mismatches, uint32_t* example);

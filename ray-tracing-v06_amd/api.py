@@ -312,11 +312,13 @@ def probe_aabb_regular(boxes, rays, max_dist, device=0):
     return reg, hit, dist
 
 
-def selftest_fastdiv(first_den, n_den, num_exp=0, den_exp=0, device=0):
-    """(mismatching pairs, example) over n_den divisor significands x all 2^23 numerator significands."""
+def selftest_fastdiv(first_den, n_den, num_exp=0, den_exp=0, device=0, four=False):
+    """(mismatching pairs, example) over n_den divisor significands x all 2^23 numerator significands;
+    four=True checks the 4-instruction two-word-reciprocal form (fast_div_exact4)."""
     bad = C.c_uint64()
     ex = np.zeros(2, np.uint32)
-    check(lib().rt_selftest_fastdiv(device, first_den, n_den, num_exp, den_exp, C.byref(bad), ex))
+    fn = lib().rt_selftest_fastdiv4 if four else lib().rt_selftest_fastdiv
+    check(fn(device, first_den, n_den, num_exp, den_exp, C.byref(bad), ex))
     return bad.value, ex
 
 

@@ -853,11 +853,12 @@ __global__ __launch_bounds__(256) void selftest_fastdiv_kernel(uint32_t first_de
     uint32_t md = first_den + blockIdx.x;
     float d = __uint_as_float(den_exp_bits | md);
     float r = 1.0f / d;
+    float rl = rcp_low_word(d, r);
     uint32_t bad = 0;
     uint32_t bad_n = 0;
     for (uint32_t mn = threadIdx.x; mn < (1u << 23); mn += 256u) {
-        float n = __uint_as_float(num_exp_bits | mn);
-        float q = fast_div_exact(n, d, r);
+        float n = __uint_as_float((num_exp_bits & ~1u) | mn);
+        float q = (num_exp_bits & 1u) ? fast_div_exact4(n, d, r, rl) : fast_div_exact(n, d, r);   // bit 0 of the exponent word = mode
         float ref = n / d;
         if (__float_as_uint(q) != __float_as_uint(ref)) { bad++; bad_n = __float_as_uint(n); }
     }
@@ -879,6 +880,23 @@ extern "C" int rt_selftest_fastdiv(int device, uint32_t first_den, uint32_t n_de
     HIP_TRY(cnt.alloc(8)); HIP_TRY(ex.alloc(8));
     HIP_TRY(hipMemset(cnt.p, 0, 8)); HIP_TRY(hipMemset(ex.p, 0, 8));
     selftest_fastdiv_kernel<<<n_den, 256>>>(first_den, (uint32_t)(num_exp + 127) << 23, (uint32_t)(den_exp + 127) << 23,
+                                            cnt.as<unsigned long long>(), ex.as<uint32_t>());
+    FINISH();
+    DOWN(mismatches, cnt, 8); DOWN(example, ex, 8);
+    return RT_OK;
+}
+
+extern "C" int rt_selftest_fastdiv4(int device, uint32_t first_den, uint32_t n_den, int32_t num_exp, int32_t den_exp,
+                                   uint64_t* mismatches, uint32_t example[2]) {
+    if (!mismatches || !example) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastdiv4: null argument");
+    if (first_den >= (1u << 23) || n_den == 0 || n_den > (1u << 23) - first_den) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastdiv4: significand range out of bounds");
+    if (num_exp < -126 || num_exp > 127 || den_exp < -126 || den_exp > 127) return rt_fail(RT_ERR_INVALID, "rt_selftest_fastdiv4: exponent out of range");
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf cnt, ex;
+    HIP_TRY(cnt.alloc(8)); HIP_TRY(ex.alloc(8));
+    HIP_TRY(hipMemset(cnt.p, 0, 8)); HIP_TRY(hipMemset(ex.p, 0, 8));
+    selftest_fastdiv_kernel<<<n_den, 256>>>(first_den, ((uint32_t)(num_exp + 127) << 23) | 1u, (uint32_t)(den_exp + 127) << 23,
                                             cnt.as<unsigned long long>(), ex.as<uint32_t>());
     FINISH();
     DOWN(mismatches, cnt, 8); DOWN(example, ex, 8);

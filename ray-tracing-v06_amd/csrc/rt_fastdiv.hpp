@@ -41,6 +41,21 @@ __device__ __forceinline__ float rcp_exact_regular(float x) {
     return __builtin_fmaf(e, r, r);
 }
 
+// The same quotient in 4 instructions, from a two-word reciprocal rh + rl ~= 1/d (rh = RN(1/d), rl = RN(rh * (1 - d*rh)),
+// both per ray):
+//      q0 = RN(n * rh)                  |q0 - n*rh| <= 1/2 ulp
+//      q1 = fma(n, rl, q0)              = RN(n/d (1 + O(2^-47)) + (q0 - n*rh)): one of the two floats around n/d (faithful)
+//      e1 = fma(-q1, d, n)              exact, since q1 is faithful
+//      q2 = fma(e1, rh, q1)             == RN(n/d)   (Markstein: rh = RN(1/d), q1 faithful)
+// Same class conditions as fast_div_exact; checked over every significand pair by rt_selftest_fastdiv (mode 1).
+__device__ __forceinline__ float rcp_low_word(float d, float rh) { return __builtin_fmaf(-d, rh, 1.0f) * rh; }
+__device__ __forceinline__ float fast_div_exact4(float n, float d, float rh, float rl) {
+    float q0 = n * rh;
+    float q1 = __builtin_fmaf(n, rl, q0);
+    float e1 = __builtin_fmaf(-q1, d, n);
+    return __builtin_fmaf(e1, rh, q1);
+}
+
 RT_HD bool coord_is_regular(float b) {  // b == 0 or 2^-40 <= |b| < 2^40
     uint32_t e;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -91,13 +106,13 @@ __device__ __forceinline__ bool aabb_intersects_regular(f3 box_min, f3 box_max, 
 // is monotone in n, and b_min <= b_max gives RN(b_min - o) <= RN(b_max - o), so the near quotient IS min(t0, t1)
 // and the far one max(t0, t1) of aabb.cuh:34-39 (up to the sign of a zero) — no v_min/v_max per axis.
 __device__ __forceinline__ bool slab_near_far_regular(float nx, float ny, float nz, float fx, float fy, float fz,
-                                                      const Ray& ray, f3 inv_d, float ray_max_dist, float& tmin_out) {
-    float tnx = fast_div_exact(nx - ray.o.x, ray.d.x, inv_d.x);
-    float tny = fast_div_exact(ny - ray.o.y, ray.d.y, inv_d.y);
-    float tnz = fast_div_exact(nz - ray.o.z, ray.d.z, inv_d.z);
-    float tfx = fast_div_exact(fx - ray.o.x, ray.d.x, inv_d.x);
-    float tfy = fast_div_exact(fy - ray.o.y, ray.d.y, inv_d.y);
-    float tfz = fast_div_exact(fz - ray.o.z, ray.d.z, inv_d.z);
+                                                      const Ray& ray, f3 inv_d, f3 inv_lo, float ray_max_dist, float& tmin_out) {
+    float tnx = fast_div_exact4(nx - ray.o.x, ray.d.x, inv_d.x, inv_lo.x);
+    float tny = fast_div_exact4(ny - ray.o.y, ray.d.y, inv_d.y, inv_lo.y);
+    float tnz = fast_div_exact4(nz - ray.o.z, ray.d.z, inv_d.z, inv_lo.z);
+    float tfx = fast_div_exact4(fx - ray.o.x, ray.d.x, inv_d.x, inv_lo.x);
+    float tfy = fast_div_exact4(fy - ray.o.y, ray.d.y, inv_d.y, inv_lo.y);
+    float tfz = fast_div_exact4(fz - ray.o.z, ray.d.z, inv_d.z, inv_lo.z);
     float tmin = fmaxf(fmaxf(tnx, tny), tnz);
     float tmax = fminf(fminf(tfx, tfy), tfz);
     tmin_out = tmin;

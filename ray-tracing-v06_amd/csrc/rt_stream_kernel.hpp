@@ -166,6 +166,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     Ray ray;
     ray.o = mk3(0.0f); ray.d = mk3(0.0f); ray.time = 0.0f;
     f3 inv_d = mk3(0.0f);   // RN(1/d) of a regular ray (EXACT == false)
+    f3 inv_lo = mk3(0.0f);  // its low word: inv_d + inv_lo ~= 1/d to 47 bits (fast_div_exact4, FAST_BVH only)
     bool regular = false;
     f3 atten = mk3(0.0f);
     f3 accum_rad = mk3(0.0f);  // EXT only: radiance emitted along the path so far
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
             inv_d = mk3(rcp_exact_regular(ray.d.x), rcp_exact_regular(ray.d.y), rcp_exact_regular(ray.d.z)); /* used by regular rays only */ \
+            if (FAST_BVH) inv_lo = mk3(rcp_low_word(ray.d.x, inv_d.x), rcp_low_word(ray.d.y, inv_d.y), rcp_low_word(ray.d.z, inv_d.z)); \
             const uint32_t km_ = (regular && FAST_BVH) ? 4u : 0u;          \
             kx = (__float_as_uint(ray.d.x) >> 29) & km_;                   \
             ky = (__float_as_uint(ray.d.y) >> 29) & km_;                   \
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS];
                         const uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
                         float tl, tr;
-                        const bool hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, rec_t, tl);
-                        const bool hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, rec_t, tr);
+                        const bool hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, inv_lo, rec_t, tl);
+                        const bool hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, inv_lo, rec_t, tr);
                         // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".

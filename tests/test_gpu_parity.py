@@ -438,17 +438,19 @@ def test_multi_pass_rendering_is_bit_identical(p, monkeypatch):
 # ------------------------------------------------------------------------------------------------
 # the 5-instruction correctly rounded division of the streaming kernel (csrc/rt_fastdiv.hpp)
 # ------------------------------------------------------------------------------------------------
-def test_fastdiv_matches_ieee_division(p):
+@pytest.mark.parametrize("four", [False, True])
+def test_fastdiv_matches_ieee_division(p, four):
     """q2 == n/d bit for bit: 64 divisor significands (incl. the all-ones and power-of-two ones) x ALL 2^23
-    numerator significands, at the centre and at the corners of the regular class's exponent range.
-    tools/verify_fastdiv.py sweeps every divisor significand (2^46 pairs); result in profiles/."""
+    numerator significands, at the centre and at the corners of the regular class's exponent range — for the
+    5-instruction form (root box, filtered variant) and the 4-instruction two-word-reciprocal form (hot loop).
+    tools/verify_fastdiv.py [--four] sweeps every divisor significand (2^46 pairs); results in profiles/."""
     rng = np.random.default_rng(21)
     special = [0, 1, 2, 3, (1 << 23) - 1, (1 << 23) - 2, 1 << 22, (1 << 22) - 1, (1 << 22) + 1, 0x2AAAAA, 0x555555]
     firsts = special + rng.integers(0, 1 << 23, 53).tolist()
     total = 0
     for k, first in enumerate(firsts):
         ne, de = [(0, 0), (-64, 39), (40, -40), (-64, -40), (40, 39)][k % 5]
-        bad, ex = p.api.selftest_fastdiv(int(first), 1, ne, de)
+        bad, ex = p.api.selftest_fastdiv(int(first), 1, ne, de, four=four)
         assert bad == 0, f"divisor significand {first:#x}: {bad} mismatches, e.g. n={ex[0]:#x} d={ex[1]:#x}"
         total += 1 << 23
     assert total == 64 << 23

@@ -13,19 +13,20 @@ import __graft_entry__ as G
 ap = argparse.ArgumentParser()
 ap.add_argument("--chunk", type=int, default=1 << 16)
 ap.add_argument("--limit", type=int, default=1 << 23, help="number of divisor significands to sweep")
+ap.add_argument("--four", action="store_true", help="check fast_div_exact4 (4 instructions, two-word reciprocal) instead of fast_div_exact")
 args = ap.parse_args()
 p = G.load_package()
 t0 = time.time()
 total_bad = 0
 for first in range(0, args.limit, args.chunk):
     n = min(args.chunk, args.limit - first)
-    bad, ex = p.api.selftest_fastdiv(first, n, 0, 0)
+    bad, ex = p.api.selftest_fastdiv(first, n, 0, 0, four=args.four)
     total_bad += bad
     done = first + n
     print(f"divisor significands [{first:#08x}, {done:#08x}): mismatches {bad}  (elapsed {time.time()-t0:.1f}s, "
           f"{done * (1 << 23) / 1e12:.2f}e12 pairs)" + (f"  example n={ex[0]:#x} d={ex[1]:#x}" if bad else ""), flush=True)
 for ne, de in [(-64, 39), (40, -40), (-64, -40), (40, 39), (-60, 0), (0, -40)]:
-    bad, ex = p.api.selftest_fastdiv(0, min(args.chunk, 1 << 14), ne, de)
+    bad, ex = p.api.selftest_fastdiv(0, min(args.chunk, 1 << 14), ne, de, four=args.four)
     total_bad += bad
     print(f"corner exponents num 2^{ne} den 2^{de}: first {min(args.chunk, 1 << 14)} divisor significands x 2^23: mismatches {bad}", flush=True)
 print(f"TOTAL mismatches: {total_bad} over {args.limit} x 2^23 significand pairs in {time.time()-t0:.1f}s")
