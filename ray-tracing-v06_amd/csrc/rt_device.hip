@@ -166,7 +166,7 @@ struct DeviceScene {
         packed.n_inner = n_inner;
         packed.n_codes = sphere_codes + w->n_quads;
         packed.n_prims = w->n_prims;
-        packed.stack_cap = true_stack ? true_stack : 1u;
+        packed.stack_cap = (true_stack ? true_stack : 1u) + 1u;  // + the sentinel entry at the bottom (RT_POP)
         packed.mats = mats.as<rt_material>();
         has_packed = true;
         return RT_OK;

@@ -114,12 +114,12 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 // A lane's status lives in `cur` alone (compares and selects are half-rate on gfx950; one register, one compare):
 //   cur <  RT_REF_IRR              at an inner node, ray in the fast-division class            } tracing
 //   cur <  RT_REF_LEAF             at an inner node (marked RT_REF_IRR: ray outside the class) }  (RT_CUR_TRACING(cur))
-//   cur <  RT_CUR_SHADE            at a leaf: RT_REF_LEAF | code                               }
+//   cur <  RT_CUR_SHADE            at a leaf: RT_REF_LEAF | code (code <= 0x7ffe)              }
 //   cur == RT_CUR_SHADE            trace finished, waiting for the shade phase
 //   cur == RT_CUR_NEED             path finished, waiting for a new sample
 //   cur == RT_CUR_OFF              no samples left
 //   cur == RT_CUR_START            got a new ray in this round; its trace begins at the end of the round
-#define RT_CUR_SHADE 0x10000u
+#define RT_CUR_SHADE 0xffffu   /* fits a 16-bit stack entry (leaf codes stop at 0x7ffe): the sentinel at the bottom of the stack */
 #define RT_CUR_NEED 0x20000u
 #define RT_CUR_OFF 0x30000u
 #define RT_CUR_START 0x40000u
@@ -175,7 +175,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
     uint32_t cur = RT_CUR_NEED;   // node reference being visited, or the lane's status (see RT_CUR_*)
-    uint16_t* sp = stack;   // next free entry of this lane's stack (entries are 64 apart)
+    uint16_t* sp = stack + 64;   // next free entry of this lane's stack (entries are 64 apart; entry 0 is the sentinel)
+    *stack = (uint16_t)RT_CUR_SHADE;
     uint32_t kx = 0, ky = 0, kz = 0;  // byte offset (0 / 4) of the (near, far) pair inside an axis triple, per ray
     // FAST_BVH: the default kernel (variant 3).  Inner references of rays outside the fast-division class are marked
     // with RT_REF_IRR (an LDS-resident tree has < 2^14 inner nodes) so that the hot loop needs no per-lane branch.
@@ -214,19 +215,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
             if (FAST_BVH && !regular && cur < RT_REF_LEAF) cur |= RT_REF_IRR; \
-            sp = stack;                                                    \
+            sp = stack + 64;                                               \
         } else {                                                           \
             cur = RT_CUR_SHADE;                                            \
         }                                                                  \
     } while (0)
+/* entry 0 of every lane's stack holds RT_CUR_SHADE: popping an empty stack IS "trace finished", no test needed */ \
 #define RT_POP()                      \
     do {                              \
-        if (sp == stack) {            \
-            cur = RT_CUR_SHADE;       \
-        } else {                      \
-            sp -= 64;                 \
-            cur = *sp;                \
-        }                             \
+        sp -= 64;                     \
+        cur = *sp;                    \
     } while (0)
 #define RT_EMIT_DARK() RT_EMIT(EXT ? accum_rad.x : 0.0f, EXT ? accum_rad.y : 0.0f, EXT ? accum_rad.z : 0.0f)
 #define RT_EMIT(rx, ry, rz)                                   \
