@@ -312,9 +312,9 @@ struct rt_renderer {
             if (stream_lds_bytes > lds_per_cu || scene.packed.n_inner >= 0x8000u || scene.packed.n_codes >= 0x8000u) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
-        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && !scene.extended) ? 3u : 2u) : 1u;
-        if (want >= 3 && scene.extended)
-            return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 render the reference's feature set only (no quads / lights / constant background): use variant 2");
+        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes) ? 3u : 2u) : 1u;
+        if (want == 4 && scene.extended)
+            return rt_fail(RT_ERR_INVALID, "kernel variant 4 renders the reference's feature set only (no quads / lights / constant background): use variant 0, 2 or 3");
         if (want >= 3 && scene.dw.kind != RT_WORLD_BVH)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need an RT_WORLD_BVH world (a HittableList / bvh_node world runs on variant 2)");
         if (want >= 2 && !can_stream)
@@ -351,7 +351,10 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
-        if (scene.extended) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true>);
+        if (scene.extended) {
+            if (variant == 3) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, true>);
+            return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true>);
+        }
         if (scene.dw.kind == RT_WORLD_LIST) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST>);
         if (scene.dw.kind == RT_WORLD_NODE_TREE) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_NODE_TREE>);
         if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768>);
