@@ -97,9 +97,12 @@ def profiled_valu(kernel_substr):
     if any(k not in v for k in need):
         return None
     cycles = v["GRBM_GUI_ACTIVE"] / 8.0
-    return {"wave_instructions_per_launch": v["SQ_INSTS_VALU"],
-            "issue_frac_of_peak": round(v["SQ_INSTS_VALU"] / (1024.0 * cycles * 0.5), 4),
-            "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0), 4)}
+    out = {"wave_instructions_per_launch": v["SQ_INSTS_VALU"],
+           "issue_frac_of_peak": round(v["SQ_INSTS_VALU"] / (1024.0 * cycles * 0.5), 4),
+           "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0), 4)}
+    if "SQ_INSTS_SALU" in v:
+        out["scalar_instructions_per_launch"] = v["SQ_INSTS_SALU"]
+    return out
 
 
 def count_leg(args):
@@ -264,7 +267,7 @@ def main():
                                "valu": profiled_valu("render_kernel_stream") if default_cfg else None,
                                "note": "algorithmic bytes = BVH node / sphere / material records the traversal touches; they are "
                                        "served from the LDS-resident scene, not HBM, so frac can exceed 1 and measured HBM traffic "
-                                       "(the 12-B-per-sample radiance buffer) is ~250x smaller: the kernel is VALU-issue bound "
+                                       "(the 12-B-per-sample radiance buffer) is ~250x smaller: the kernel is instruction-issue bound (the peak of issue_frac_of_peak is the 2-cycle fp32 add/mul/fma rate; compares, selects, min/max cost 4 cycles and scalar instructions are not hidden) "
                                        "(DESIGN.md §7)"}
             if base is not None:
                 out["cpu_baseline"] = base
