@@ -250,6 +250,10 @@ int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float* d_out);
 /* HIP-event time of the last render launch(es) in ms (cudaTimer twin,
  * Renderer.cu:127-136).  Synchronises on the events.                        */
 int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms);
+/* Which kernel the renderer resolved to: out[0] = variant actually used (1..4), out[1] = 1 when the scene image is
+ * LDS-resident (0: baseline kernel, or a world too large for the LDS, served from global memory / L2 with 32-bit
+ * references), out[2] = workgroup size, out[3] = workgroups per CU.                                              */
+int rt_renderer_kernel_info(rt_renderer* r, uint32_t out[4]);
 /* Renderer::DownloadRenderbuffer (Renderer.cu:94-96): width*height*4 floats,
  * row-major, row 0 = bottom.  Only valid for world_size == 1.               */
 int rt_renderer_download(rt_renderer* r, float* host_rgba, size_t n_floats);

@@ -211,6 +211,12 @@ class Renderer:
         check(lib().rt_renderer_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def kernel_info(self):
+        """{'variant', 'lds_resident', 'workgroup', 'workgroups_per_cu'} the renderer resolved to."""
+        out = (C.c_uint32 * 4)()
+        check(lib().rt_renderer_kernel_info(self.h, C.byref(out)))
+        return {"variant": out[0], "lds_resident": bool(out[1]), "workgroup": out[2], "workgroups_per_cu": out[3]}
+
     def DownloadRenderbuffer(self):
         out = np.zeros((self.cfg.height, self.cfg.width, 4), dtype=np.float32)
         check(lib().rt_renderer_download(self.h, out, out.size))

@@ -66,7 +66,7 @@ SYMBOLS = [
     "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list", "rt_scene_add_bvh_node",
     "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
     "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
-    "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_download", "rt_renderer_shard_floats",
+    "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_kernel_info", "rt_renderer_download", "rt_renderer_shard_floats",
     "rt_renderer_assemble", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
     "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_aabb_regular", "rt_probe_boxpair_filtered",
     "rt_selftest_fastdiv", "rt_selftest_fastdiv4", "rt_selftest_fastrcp", "rt_device_count", "rt_version",
@@ -144,6 +144,7 @@ def lib():
     L.rt_renderer_render.argtypes = [C.c_void_p]
     L.rt_renderer_render_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_renderer_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
+    L.rt_renderer_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32 * 4)]
     L.rt_renderer_download.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.rt_renderer_shard_floats.argtypes = [C.c_void_p, P(C.c_size_t)]
     L.rt_renderer_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -51,15 +51,16 @@ struct DevBuf {
 };
 
 // one wide node of the LDS image (layout: rt_stream_kernel.hpp): per child box and axis the triple (min, max, min)
-static void write_wide_node(uint4* blob, uint32_t index, const float lmin[3], const float lmax[3], const float rmin[3],
+static void write_wide_node(uint4* blob, bool big, uint32_t index, const float lmin[3], const float lmax[3], const float rmin[3],
                             const float rmax[3], uint32_t lref, uint32_t rref) {
-    uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * RT_NODE_DWORDS;
+    uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * (big ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS);
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
     for (int k = 0; k < 3; k++) {
         d[3 * k + 0] = bits(lmin[k]); d[3 * k + 1] = bits(lmax[k]); d[3 * k + 2] = bits(lmin[k]);
         d[9 + 3 * k + 0] = bits(rmin[k]); d[9 + 3 * k + 1] = bits(rmax[k]); d[9 + 3 * k + 2] = bits(rmin[k]);
     }
-    d[RT_NODE_REFS] = (lref & 0xffffu) | (rref << 16);
+    if (big) { d[RT_NODE_REFS] = lref; d[RT_NODE_REFS + 1] = rref; }
+    else d[RT_NODE_REFS] = (lref & 0xffffu) | (rref << 16);
 }
 
 struct DeviceScene {
@@ -70,18 +71,23 @@ struct DeviceScene {
     bool has_packed = false;
     uint32_t true_stack = 0;  // traversal-stack bound computed from the tree itself
     bool regular_boxes = false;  // all box coordinates inside the fast-division class
+    bool big = false;            // packed with 32-bit references for the global-memory kernel (does not fit the LDS)
 
     // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 76-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
-    int pack(const rt_world_flat* w) {
+    // want_big: 32-bit references, records read from global memory (for worlds whose image does not fit the LDS)
+    int pack(const rt_world_flat* w, bool want_big) {
         has_packed = false;
         regular_boxes = false;
+        big = want_big;
+        const uint32_t ref_leaf = big ? RT_REF_LEAF_BIG : RT_REF_LEAF, ref_irr = big ? RT_REF_IRR_BIG : RT_REF_IRR;
         const uint32_t sphere_codes = w->n_prims * 2u;
-        if (sphere_codes + w->n_quads >= RT_REF_LEAF || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // 16-bit references would not fit
-        if (extended && w->kind != RT_WORLD_BVH) return RT_OK;  // quads / lights / background: the LDS kernel takes them in BVH worlds only
+        if ((uint64_t)w->n_prims * 2u + w->n_quads >= (big ? 0x7ffffff0ull : (uint64_t)RT_REF_LEAF - 1u) || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // references would not fit
+        if (big && w->kind != RT_WORLD_BVH) return RT_OK;
+        if (extended && w->kind != RT_WORLD_BVH) return RT_OK;  // quads / lights / background: the streaming kernel takes them in BVH worlds only
         auto leaf_ref = [&](uint32_t prim) -> uint32_t {  // unified primitive index -> leaf reference
-            if (prim >= w->n_prims) return RT_REF_LEAF | (sphere_codes + (prim - w->n_prims));
-            return RT_REF_LEAF | (prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u));
+            if (prim >= w->n_prims) return ref_leaf | (sphere_codes + (prim - w->n_prims));
+            return ref_leaf | (prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u));
         };
         auto mat_bits = [&](uint32_t mi, uint32_t moving) -> uint32_t { return mi | (moving << 28) | (w->materials[mi].type << 29); };
         // wide nodes: BVH -> one per inner node, holding BOTH child boxes; bvh_node tree -> one per node, holding its OWN box
@@ -93,8 +99,8 @@ struct DeviceScene {
         } else if (w->kind == RT_WORLD_NODE_TREE) {
             n_inner = w->n_nodes;
         }
-        if (n_inner >= RT_REF_LEAF) return RT_OK;
-        const uint32_t nodes_vec4 = RT_NODES_VEC4(n_inner);
+        if (n_inner >= ref_leaf) return RT_OK;
+        const uint32_t nodes_vec4 = RT_NODES_VEC4(n_inner, big);
         size_t n_vec4 = (size_t)nodes_vec4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials + (size_t)w->n_quads * 5;
         std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));
         if (w->kind == RT_WORLD_BVH) {
@@ -107,12 +113,12 @@ struct DeviceScene {
                 const rt_bvh_node& n = w->nodes[i];
                 const rt_bvh_node& l = w->nodes[n.left];
                 const rt_bvh_node& r = w->nodes[n.right];
-                write_wide_node(host.data(), (uint32_t)wide_of[i], l.min, l.max, r.min, r.max, ref_of(n.left), ref_of(n.right));
+                write_wide_node(host.data(), big, (uint32_t)wide_of[i], l.min, l.max, r.min, r.max, ref_of(n.left), ref_of(n.right));
             }
             packed.root_ref = ref_of(w->root);
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->nodes[w->root].min[k]; packed.root_max[k] = w->nodes[w->root].max[k]; }
             // rt_fastdiv.hpp condition (a): every box coordinate is 0 or 2^-40 <= |b| < 2^40, boxes not inverted
-            regular_boxes = n_inner < RT_REF_IRR;  // the fast kernel marks references with bit 14
+            regular_boxes = n_inner < ref_irr;  // the fast kernel marks references with the bit below the leaf bit
             for (uint32_t i = 0; i < w->n_nodes && regular_boxes; i++)
                 for (int k = 0; k < 3; k++)
                     if (!coord_is_regular(w->nodes[i].min[k]) || !coord_is_regular(w->nodes[i].max[k]) || !(w->nodes[i].min[k] <= w->nodes[i].max[k]))
@@ -122,12 +128,12 @@ struct DeviceScene {
             for (uint32_t i = 0; i < w->n_nodes; i++) {
                 const rt_bvh_node& n = w->nodes[i];
                 const float zero[3] = {0.0f, 0.0f, 0.0f};
-                write_wide_node(host.data(), i, n.min, n.max, zero, zero, ref_of(n.left), ref_of(n.right));
+                write_wide_node(host.data(), big, i, n.min, n.max, zero, zero, ref_of(n.left), ref_of(n.right));
             }
             packed.root_ref = ref_of(w->root);
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->bounds_min[k]; packed.root_max[k] = w->bounds_max[k]; }
         } else {  // HittableList: reference = RT_REF_LEAF | primitive index, pre-test against the world bounds
-            packed.root_ref = RT_REF_LEAF | 0u;
+            packed.root_ref = ref_leaf | 0u;
             for (int k = 0; k < 3; k++) { packed.root_min[k] = w->bounds_min[k]; packed.root_max[k] = w->bounds_max[k]; }
         }
         float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)nodes_vec4);
@@ -244,7 +250,14 @@ struct DeviceScene {
         dw.quads = quads.as<rt_quad>(); dw.n_quads = w->n_quads;
         dw.background = w->background;
         dw.background_color = mk3(w->background_color[0], w->background_color[1], w->background_color[2]);
-        return pack(w);
+        // 16-bit references and an LDS-resident image when that fits (2 x 768-thread workgroups per CU want <= 80 KiB each,
+        // one workgroup may take all 160 KiB); otherwise 32-bit references and the records stay in global memory / L2
+        int rc = pack(w, false);
+        if (rc != RT_OK) return rc;
+        const bool fits_lds = has_packed && (size_t)packed.blob_vec4 * 16u + (size_t)RT_STREAM_BLOCK * packed.stack_cap * 2u <= 160u * 1024u;
+        const char* force = std::getenv("RT06_FORCE_BIG");  // measurements / tests: take the global-memory path for any BVH world
+        if ((!fits_lds || (force && force[0] == '1')) && w->kind == RT_WORLD_BVH) rc = pack(w, true);
+        return rc;
     }
 };
 
@@ -307,22 +320,29 @@ struct rt_renderer {
                 int v = std::atoi(env);
                 if (v == 512 || v == 768 || v == 1024) stream_block = (uint32_t)v;
             }
-            stream_lds_bytes = scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u;
-            stream_lds_bytes = (stream_lds_bytes + 15u) & ~15u;
-            if (stream_lds_bytes > lds_per_cu || scene.packed.n_inner >= 0x8000u || scene.packed.n_codes >= 0x8000u) can_stream = false;
+            if (scene.big) {  // only the per-lane stacks (32-bit entries) live in the LDS
+                stream_block = RT_STREAM_BLOCK;
+                stream_lds_bytes = (stream_block * scene.packed.stack_cap * 4u + 15u) & ~15u;
+            } else {
+                stream_lds_bytes = scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u;
+                stream_lds_bytes = (stream_lds_bytes + 15u) & ~15u;
+            }
+            if (stream_lds_bytes > lds_per_cu) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
         if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes) ? 3u : 2u) : 1u;
+        if (want == 4 && can_stream && scene.big)
+            return rt_fail(RT_ERR_INVALID, "kernel variant 4 needs a world whose LDS image fits in 160 KiB: use variant 0, 2 or 3");
         if (want == 4 && scene.extended)
             return rt_fail(RT_ERR_INVALID, "kernel variant 4 renders the reference's feature set only (no quads / lights / constant background): use variant 0, 2 or 3");
         if (want >= 3 && scene.dw.kind != RT_WORLD_BVH)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need an RT_WORLD_BVH world (a HittableList / bvh_node world runs on variant 2)");
         if (want >= 2 && !can_stream)
-            return rt_fail(RT_ERR_INVALID, "kernel variant %u needs a world whose LDS image fits in 160 KiB", want);
+            return rt_fail(RT_ERR_INVALID, "kernel variant %u cannot take this world (HittableList / bvh_node worlds must fit the 160 KiB LDS)", want);
         if (want >= 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
-        if (variant == 2 || variant == 4) {
+        if ((variant == 2 || variant == 4) && !scene.big) {
             stream_block = 768;
             stream_lds_bytes = (scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u + 15u) & ~15u;
             stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
@@ -351,6 +371,10 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
+        if (scene.big) {
+            if (variant == 3) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, true, true>);
+            return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true, true>);
+        }
         if (scene.extended) {
             if (variant == 3) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, true>);
             return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true>);
@@ -505,6 +529,15 @@ extern "C" int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms) {
     HIP_TRY(hipSetDevice(r->cfg.device));
     HIP_TRY(hipEventSynchronize(r->ev1));
     HIP_TRY(hipEventElapsedTime(out_ms, r->ev0, r->ev1));
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_kernel_info(rt_renderer* r, uint32_t out[4]) {
+    if (!r || !out) return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_info: null argument");
+    out[0] = r->variant;
+    out[1] = (r->variant >= 2 && !r->scene.big) ? 1u : 0u;
+    out[2] = r->variant >= 2 ? r->stream_block : 64u;
+    out[3] = r->variant >= 2 ? r->stream_blocks_per_cu : 0u;
     return RT_OK;
 }
 

@@ -27,6 +27,7 @@
 //    bit-identical to the CPU oracle's, and independent of scheduling and of the number of GPUs.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "rt06.h"
 #include "rt_device_funcs.hpp"
@@ -58,8 +59,15 @@
 #define RT_NODE_DWORDS 19u
 #define RT_NODE_BYTES (RT_NODE_DWORDS * 4u)
 #define RT_NODE_REFS 18u
+// BIG scenes (the image does not fit the LDS, or has 2^14 inner nodes / 2^15 leaf codes or more): the same records are
+// read from global memory (they stay L2-resident) and references are 32 bits wide — a wide node is 20 dwords with the
+// left / right reference in dwords 18 / 19, bit 31 marks a leaf, bit 30 a ray outside the fast class; the per-lane
+// stacks (32-bit entries) are all that lives in the LDS.
+#define RT_REF_LEAF_BIG 0x80000000u
+#define RT_REF_IRR_BIG 0x40000000u
+#define RT_NODE_DWORDS_BIG 20u
 // number of 16-B units the node region of `n` wide nodes occupies in the blob
-#define RT_NODES_VEC4(n) (((n) * RT_NODE_DWORDS + 3u) / 4u)
+#define RT_NODES_VEC4(n, big) (((n) * ((big) ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) + 3u) / 4u)
 
 // LDS image, in 16-B units:  [wide nodes (RT_NODE_DWORDS dwords each, region rounded up) | spheres (c0, r) | extra (c1, matbits) | mats16 (albedo, param) |
 //                              quads (5 each: Q,D | u,matbits | v | normal | w)],   matbits = material index | moving << 28 | type << 29
@@ -115,15 +123,13 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 //   cur <  RT_REF_IRR              at an inner node, ray in the fast-division class            } tracing
 //   cur <  RT_REF_LEAF             at an inner node (marked RT_REF_IRR: ray outside the class) }  (RT_CUR_TRACING(cur))
 //   cur <  RT_CUR_SHADE            at a leaf: RT_REF_LEAF | code (code <= 0x7ffe)              }
-//   cur == RT_CUR_SHADE            trace finished, waiting for the shade phase
-//   cur == RT_CUR_NEED             path finished, waiting for a new sample
-//   cur == RT_CUR_OFF              no samples left
-//   cur == RT_CUR_START            got a new ray in this round; its trace begins at the end of the round
-#define RT_CUR_SHADE 0xffffu   /* fits a 16-bit stack entry (leaf codes stop at 0x7ffe): the sentinel at the bottom of the stack */
-#define RT_CUR_NEED 0x20000u
-#define RT_CUR_OFF 0x30000u
-#define RT_CUR_START 0x40000u
-#define RT_CUR_TRACING(c) ((c) < RT_CUR_SHADE)
+//   cur == K_SHADE                 trace finished, waiting for the shade phase
+//   cur == K_NEED                  path finished, waiting for a new sample
+//   cur == K_OFF                   no samples left
+//   cur == K_START                 got a new ray in this round; its trace begins at the end of the round
+// Values (K_* constants inside the kernel): 16-bit references: SHADE 0xffff (fits a stack entry: the sentinel at the bottom of
+// the stack; leaf codes stop at 0x7ffe), NEED 0x20000, OFF 0x30000, START 0x40000; 32-bit references (BIG): the top four
+// values 0xfffffffc .. 0xffffffff.  "Tracing" is `cur < K_SHADE` either way.
 
 // EXACT = true : box tests use aabb_intersects() verbatim (IEEE division, GLM min/max).
 // EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
@@ -139,24 +145,37 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 //        leaf codes >= sphere_codes are quads, emitted radiance is accumulated along the path (the reference's
 //        commented `accum_radiance`), the miss colour may be a constant.  A separate instantiation, so the
 //        reference-feature kernels carry none of it.
-template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, bool EXT = false>
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, bool EXT = false, bool BIG = false>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
 
-    // ---- stage the scene blob: coalesced 16 B per lane --------------------------------------------
-    for (uint32_t i = tid; i < p.scene.blob_vec4; i += BLOCK) lds[i] = p.scene.blob[i];
-    __syncthreads();
+    // reference encoding and lane status codes (see the header of this file)
+    using ref_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
+    constexpr uint32_t K_LEAF = BIG ? RT_REF_LEAF_BIG : RT_REF_LEAF, K_IRR = BIG ? RT_REF_IRR_BIG : RT_REF_IRR;
+    constexpr uint32_t K_SHADE = BIG ? 0xfffffffcu : 0xffffu, K_NEED = BIG ? 0xfffffffdu : 0x20000u;
+    constexpr uint32_t K_OFF = BIG ? 0xfffffffeu : 0x30000u, K_START = BIG ? 0xffffffffu : 0x40000u;
+    constexpr uint32_t K_NODE_BYTES = (BIG ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) * 4u;
+    static_assert(!BIG || WORLD == RT_WORLD_BVH, "BIG scenes are BVH worlds");
 
-    const char* nodes = reinterpret_cast<const char*>(lds);
-    const float4* spheres = reinterpret_cast<const float4*>(lds + p.scene.off_spheres);
-    const float4* extra = reinterpret_cast<const float4*>(lds + p.scene.off_extra);
-    const float4* mats16 = reinterpret_cast<const float4*>(lds + p.scene.off_mats);
-    const float4* quads = reinterpret_cast<const float4*>(lds + p.scene.off_quads);
-    // per-lane traversal stack of 16-bit references.  Entry k of this lane is stack[k * 64].
-    uint16_t* stack = reinterpret_cast<uint16_t*>(lds + p.scene.blob_vec4) + wave * 64u * p.scene.stack_cap + lane;
+    // ---- the scene: staged into the LDS with coalesced 16-B loads, or (BIG) left in global memory / L2 -------------
+    const uint4* scene_base;
+    if (BIG) {
+        scene_base = p.scene.blob;
+    } else {
+        for (uint32_t i = tid; i < p.scene.blob_vec4; i += BLOCK) lds[i] = p.scene.blob[i];
+        __syncthreads();
+        scene_base = lds;
+    }
+    const char* nodes = reinterpret_cast<const char*>(scene_base);
+    const float4* spheres = reinterpret_cast<const float4*>(scene_base + p.scene.off_spheres);
+    const float4* extra = reinterpret_cast<const float4*>(scene_base + p.scene.off_extra);
+    const float4* mats16 = reinterpret_cast<const float4*>(scene_base + p.scene.off_mats);
+    const float4* quads = reinterpret_cast<const float4*>(scene_base + p.scene.off_quads);
+    // per-lane traversal stack of references (16 bits, BIG: 32).  Entry k of this lane is stack[k * 64].
+    ref_t* stack = reinterpret_cast<ref_t*>(lds + (BIG ? 0u : p.scene.blob_vec4)) + wave * 64u * p.scene.stack_cap + lane;
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
@@ -174,12 +193,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
-    uint32_t cur = RT_CUR_NEED;   // node reference being visited, or the lane's status (see RT_CUR_*)
-    uint16_t* sp = stack + 64;   // next free entry of this lane's stack (entries are 64 apart; entry 0 is the sentinel)
-    *stack = (uint16_t)RT_CUR_SHADE;
+    uint32_t cur = K_NEED;   // node reference being visited, or the lane's status (see RT_CUR_*)
+    ref_t* sp = stack + 64;   // next free entry of this lane's stack (entries are 64 apart; entry 0 is the sentinel)
+    *stack = (ref_t)K_SHADE;
     uint32_t kx = 0, ky = 0, kz = 0;  // byte offset (0 / 4) of the (near, far) pair inside an axis triple, per ray
     // FAST_BVH: the default kernel (variant 3).  Inner references of rays outside the fast-division class are marked
-    // with RT_REF_IRR (an LDS-resident tree has < 2^14 inner nodes) so that the hot loop needs no per-lane branch.
+    // with K_IRR (an LDS-resident tree has < 2^14 inner nodes) so that the hot loop needs no per-lane branch.
     constexpr bool FAST_BVH = !EXACT && !FILTER && WORLD == RT_WORLD_BVH;
     bool irr_pending = false;         // wave-uniform: some lane is traversing with a ray outside the class
     uint32_t depth = 0;
@@ -214,13 +233,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
-            if (FAST_BVH && !regular && cur < RT_REF_LEAF) cur |= RT_REF_IRR; \
+            if (FAST_BVH && !regular && cur < K_LEAF) cur |= K_IRR; \
             sp = stack + 64;                                               \
         } else {                                                           \
-            cur = RT_CUR_SHADE;                                            \
+            cur = K_SHADE;                                            \
         }                                                                  \
     } while (0)
-/* entry 0 of every lane's stack holds RT_CUR_SHADE: popping an empty stack IS "trace finished", no test needed */ \
+/* entry 0 of every lane's stack holds K_SHADE: popping an empty stack IS "trace finished", no test needed */ \
 #define RT_POP()                      \
     do {                              \
         sp -= 64;                     \
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     do {                                                      \
         float* o_ = p.samples + (size_t)out_idx * 3u;         \
         o_[0] = (rx); o_[1] = (ry); o_[2] = (rz);             \
-        cur = RT_CUR_NEED;                                    \
+        cur = K_NEED;                                    \
     } while (0)
 
 #ifdef RT_PHASE_TIMERS
@@ -246,22 +265,22 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         // ================= phase 1: inner-node steps (BVH.cu:76-97) ==================================
         if (FAST_BVH) {
             // Hot loop of the default kernel: lanes whose ray is in the fast-division class (all but a handful).  The
-            // step is straight-line code; lanes outside the class carry RT_REF_IRR in their inner references, so they
-            // fail `cur < RT_REF_IRR` here and are stepped by the verbatim loop below.
-            bool at_inner = cur < RT_REF_IRR;
+            // step is straight-line code; lanes outside the class carry K_IRR in their inner references, so they
+            // fail `cur < K_IRR` here and are stepped by the verbatim loop below.
+            bool at_inner = cur < K_IRR;
             if (__ballot(at_inner) != 0ull) {
                 uint32_t n_inner_lanes;
                 do {
                     if (at_inner) {
-                        const char* nb = nodes + cur * RT_NODE_BYTES;
+                        const char* nb = nodes + cur * K_NODE_BYTES;
                         const float* px = reinterpret_cast<const float*>(nb + kx);
                         const float* py = reinterpret_cast<const float*>(nb + ky);
                         const float* pz = reinterpret_cast<const float*>(nb + kz);
                         const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
                         const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
                         const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
-                        const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS];
-                        const uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
+                        const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS], refs_hi = BIG ? reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS + 1u] : 0u;
+                        const uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
                         float tl, tr;
                         const bool hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, inv_lo, rec_t, tl);
                         const bool hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, inv_lo, rec_t, tr);
@@ -270,13 +289,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".
                         const bool go_right = hr && (!hl || tl > tr);
                         if (hl && hr) {
-                            *sp = (uint16_t)(go_right ? left_idx : right_idx);
+                            *sp = (ref_t)(go_right ? left_idx : right_idx);
                             sp += 64;
                         }
                         cur = go_right ? right_idx : left_idx;
                         if (!(hl || hr)) RT_POP();
                     }
-                    at_inner = cur < RT_REF_IRR;
+                    at_inner = cur < K_IRR;
                     n_inner_lanes = (uint32_t)__popcll(__ballot(at_inner));
 #ifdef RT_PHASE_TIMERS
                     pc_[6]++;
@@ -286,35 +305,35 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             RT_PT(0);
             if (irr_pending) {   // wave-uniform, rare: rays with a zero / tiny / huge direction or origin component
                 for (;;) {
-                    const bool at_irr = (cur & (RT_REF_LEAF | RT_REF_IRR)) == RT_REF_IRR;
+                    const bool at_irr = (cur & (K_LEAF | K_IRR)) == K_IRR;
                     if (__ballot(at_irr) == 0ull) break;
                     if (at_irr) {
-                        const float* nf = reinterpret_cast<const float*>(nodes + (cur & (RT_REF_IRR - 1u)) * RT_NODE_BYTES);
-                        uint32_t refs = reinterpret_cast<const uint32_t*>(nf)[RT_NODE_REFS];
-                        uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
-                        if (left_idx < RT_REF_LEAF) left_idx |= RT_REF_IRR;     // inner references stay marked all the way down
-                        if (right_idx < RT_REF_LEAF) right_idx |= RT_REF_IRR;
+                        const float* nf = reinterpret_cast<const float*>(nodes + (cur & (K_IRR - 1u)) * K_NODE_BYTES);
+                        const uint32_t refs = reinterpret_cast<const uint32_t*>(nf)[RT_NODE_REFS], refs_hi = BIG ? reinterpret_cast<const uint32_t*>(nf)[RT_NODE_REFS + 1u] : 0u;
+                        uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
+                        if (left_idx < K_LEAF) left_idx |= K_IRR;     // inner references stay marked all the way down
+                        if (right_idx < K_LEAF) right_idx |= K_IRR;
                         float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
                         const bool hl = aabb_intersects(mk3(nf[0], nf[3], nf[6]), mk3(nf[1], nf[4], nf[7]), ray, rec_t, left_dist);
                         const bool hr = aabb_intersects(mk3(nf[9], nf[12], nf[15]), mk3(nf[10], nf[13], nf[16]), ray, rec_t, right_dist);
                         const bool swap_lr = left_dist > right_dist;
                         if (hl && hr) {
-                            *sp = (uint16_t)(swap_lr ? left_idx : right_idx);
+                            *sp = (ref_t)(swap_lr ? left_idx : right_idx);
                             sp += 64;
                         }
                         cur = (swap_lr || !hl) ? right_idx : left_idx;
                         if (!(hl || hr)) RT_POP();
                     }
                 }
-                irr_pending = __ballot(!regular && RT_CUR_TRACING(cur)) != 0ull;
+                irr_pending = __ballot(!regular && (cur < K_SHADE)) != 0ull;
             }
             RT_PT(1);
         } else {
-            bool at_inner = cur < RT_REF_LEAF;
+            bool at_inner = cur < K_LEAF;
             uint64_t m_inner = __ballot(at_inner);
             while (m_inner != 0ull) {
                 if (at_inner) {
-                    const char* nb = nodes + cur * RT_NODE_BYTES;
+                    const char* nb = nodes + cur * K_NODE_BYTES;
                     // (near, far) plane pairs of the three axes; kx/ky/kz are 0 in these kernels: near == box min, far == box max
                     const float* px = reinterpret_cast<const float*>(nb + kx);
                     const float* py = reinterpret_cast<const float*>(nb + ky);
@@ -322,13 +341,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
                     const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
                     const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
-                    const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS];
-                    const uint32_t left_idx = refs & 0xffffu, right_idx = refs >> 16;
+                    const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS], refs_hi = BIG ? reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS + 1u] : 0u;
+                    const uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
                     if (WORLD == RT_WORLD_NODE_TREE) {
                         // bvh_node::ClosestIntersection (bvh_node.cuh:19-24): own box, then left subtree, then right
                         float d_own;
                         if (aabb_intersects(mk3(lnx, lny, lnz), mk3(lfx, lfy, lfz), ray, rec_t, d_own)) {
-                            *sp = (uint16_t)right_idx;
+                            *sp = (ref_t)right_idx;
                             sp += 64;
                             cur = left_idx;
                         } else {
@@ -362,14 +381,14 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         // child is pushed and the near one (which would be popped straight away) stays in `cur`; with one
                         // hit it becomes `cur` (swap_lr is then exactly "the right one"); with none the stack is popped.
                         if (hl && hr) {
-                            *sp = (uint16_t)(swap_lr ? left_idx : right_idx);
+                            *sp = (ref_t)(swap_lr ? left_idx : right_idx);
                             sp += 64;
                         }
                         cur = (swap_lr || !hl) ? right_idx : left_idx;
                         if (!(hl || hr)) RT_POP();
                     }
                 }
-                at_inner = cur < RT_REF_LEAF;
+                at_inner = cur < K_LEAF;
                 m_inner = __ballot(at_inner);
                 if ((uint32_t)__popcll(m_inner) < p.inner_keep) break;
             }
@@ -377,11 +396,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
         {
-            bool at_leaf = (cur - RT_REF_LEAF) < (RT_CUR_SHADE - RT_REF_LEAF);
+            bool at_leaf = (cur - K_LEAF) < (K_SHADE - K_LEAF);
             uint64_t m_leaf = __ballot(at_leaf);
-            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < RT_REF_LEAF) == 0ull)) {
+            if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < K_LEAF) == 0ull)) {
                 if (at_leaf) {
-                    uint32_t code = cur & 0x7fffu;   // BVH / tree: prim * 2 + is_moving;  list: prim
+                    uint32_t code = cur & (K_LEAF - 1u);   // BVH / tree: prim * 2 + is_moving;  list: prim
                     if (EXT && code >= p.scene.sphere_codes) {
                         // quad::hit ("The Next Week"), reference conventions: see quad_closest_intersection()
                         const float4* qd = quads + (code - p.scene.sphere_codes) * 5u;
@@ -413,8 +432,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         rec_code = (int32_t)code;
                     }
                     if (WORLD == RT_WORLD_LIST) {  // HittableList.cuh:26-30: every object, in order
-                        if (prim + 1u < p.scene.n_prims) cur = RT_REF_LEAF | (prim + 1u);
-                        else cur = RT_CUR_SHADE;
+                        if (prim + 1u < p.scene.n_prims) cur = K_LEAF | (prim + 1u);
+                        else cur = K_SHADE;
                     } else {
                         RT_POP();
                     }
@@ -427,12 +446,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         // ================= phase 3: shade finished traces, regenerate finished paths ==================
         // lanes that are not tracing wait for this phase (switched-off lanes count as waiting: near the end of the
         // pass that only makes the phase run a little earlier)
-        uint64_t m_trav = __ballot(RT_CUR_TRACING(cur));
+        uint64_t m_trav = __ballot((cur < K_SHADE));
         if (64u - (uint32_t)__popcll(m_trav) < p.shade_min && m_trav != 0ull) continue;
 
         bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
         RT_PT(8);
-        if (cur == RT_CUR_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
+        if (cur == K_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
             if (rec_code < 0) {
                 f3 sky;
                 if (EXT && p.scene.background == 1u) {
@@ -536,7 +555,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         RT_PT(3);
         // ---- hand new samples to the lanes that need one (wave-uniform loop) -------------------------
         for (;;) {
-            uint64_t m_need = __ballot(cur == RT_CUR_NEED);
+            uint64_t m_need = __ballot(cur == K_NEED);
             if (m_need == 0ull) break;
             if (pool_next == pool_end) {
                 if (pool_dry) break;
@@ -553,7 +572,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             }
             uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(m_need));
             uint32_t rank = lane_rank(m_need);
-            if (cur == RT_CUR_NEED && rank < take) {
+            if (cur == K_NEED && rank < take) {
                 // sample index n -> (64-pixel block, sample, pixel in block): n = (blk * pass_spp + s) * 64 + pix
                 uint32_t rem = pool_rem + rank;
                 bool second = rem >= spb;  // rank < 64 <= spb: at most one block boundary
@@ -577,7 +596,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         RT_EMIT(0.0f, 0.0f, 0.0f);
                     } else {
                         start_trace = true;
-                        cur = RT_CUR_START;  // no longer RT_CUR_NEED, so the loop does not hand it another sample
+                        cur = K_START;  // no longer K_NEED, so the loop does not hand it another sample
                     }
                 }
                 // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
@@ -594,9 +613,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         RT_PT(4);
         if (start_trace) RT_BEGIN_TRACE();
         if (FAST_BVH && __ballot(start_trace && !regular) != 0ull) irr_pending = true;
-        if (pool_dry && cur == RT_CUR_NEED) cur = RT_CUR_OFF;
+        if (pool_dry && cur == K_NEED) cur = K_OFF;
         RT_PT(5);
-        if (__ballot(cur != RT_CUR_OFF) == 0ull) break;
+        if (__ballot(cur != K_OFF) == 0ull) break;
     }
 #ifdef RT_PHASE_TIMERS
     if (lane == 0)

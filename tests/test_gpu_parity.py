@@ -676,3 +676,72 @@ def test_random_scenes_cameras_and_builders_render_bit_exact(p, seed):
     img, ref = _render_both(p, s, cam, W, H, spp, depth=depth)
     assert np.array_equal(np.isnan(img), np.isnan(ref))
     assert bits_equal(img, ref), f"seed {seed} builder {builder} cam {cam_kind} {W}x{H}x{spp} depth {depth}: " + mismatch_report(img, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+# worlds that do not fit the LDS: same streaming kernel, records from global memory, 32-bit references
+# ------------------------------------------------------------------------------------------------
+def _big_sphere_scene(p, n, seed, lights_and_quads=False):
+    rng = np.random.default_rng(seed)
+    s = p.Scene()
+    mats = [s.Lambertian((0.7, 0.3, 0.3)), s.Metal((0.8, 0.8, 0.9), 0.1), s.Dielectric((1, 1, 1), 1.5),
+            s.LambertianTexture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9), 0.32), s.Lambertian((0.3, 0.3, 0.8))]
+    if lights_and_quads:
+        mats.append(s.DiffuseLight((4.0, 4.0, 3.0)))
+    s.MakeSphere((0, -1000.0, 0), 1000.0, mats[3])
+    for i in range(n):
+        c = ((rng.random(3) * 2 - 1) * np.array([30, 0, 30]) + np.array([0, 0.2 + rng.random() * 3, 0])).astype(np.float32)
+        r = float(0.05 + rng.random() * 0.25)
+        m = mats[int(rng.integers(0, len(mats)))]
+        if i % 7 == 0:
+            s.MakeMovingSphere(c, c + np.float32([0, 0.3, 0]), r, m)
+        else:
+            s.MakeSphere(c, r, m)
+    if lights_and_quads:
+        for i in range(40):
+            Q = ((rng.random(3) * 2 - 1) * np.array([25, 0, 25]) + np.array([0, 0.5 + rng.random() * 4, 0])).astype(np.float32)
+            s.MakeQuad(Q, np.float32([rng.random() + 0.3, 0, 0]), np.float32([0, rng.random() + 0.3, rng.random()]), mats[int(rng.integers(0, len(mats)))])
+        s.set_background((0.02, 0.03, 0.05))
+    s.BuildBVH_TopDown()
+    return s
+
+
+@pytest.mark.parametrize("ext", [False, True])
+def test_world_larger_than_the_lds_renders_bit_exact_from_global_memory(p, ext):
+    """3000 spheres = 2999 wide nodes = 228 KB of node records alone: more than the 160 KiB LDS.  The renderer must keep
+    the streaming kernel (not fall back to the wave-per-pixel baseline) and the framebuffer must still equal the oracle's."""
+    s = _big_sphere_scene(p, 2999, 77, lights_and_quads=ext)
+    W, H, spp = 120, 80, 6
+    cam = p.DefocusBlurCamera((26, 4, 6), (0, 1, 0), (0, 1, 0), 35.0, W / H, 0.05, 24.0)
+    w = s.getWorldPtr()
+    assert w.n_nodes >= 5999
+    for variant in (0, 2):
+        r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, variant=variant)
+        info = r.kernel_info()
+        assert info["variant"] == (3 if variant == 0 else 2) and not info["lds_resident"], info
+        r.Render()
+        img = r.DownloadRenderbuffer()
+        r.close()
+        ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, 50)
+        assert bits_equal(img, ref), f"variant {variant}: " + mismatch_report(img, ref)
+    with pytest.raises(p.capi.RtError, match="variant 4"):
+        p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, variant=4)
+
+
+def test_lds_and_global_memory_paths_agree_on_the_book_scene(p, monkeypatch):
+    """RT06_FORCE_BIG=1 sends a world that WOULD fit the LDS down the global-memory path: same bits."""
+    W, H, spp = 200, 120, 10
+    s = config_scene(p, "book1_final")
+    cam = config_cameras(p, "book1_final", W, H)
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr())
+    assert r.kernel_info() == {"variant": 3, "lds_resident": True, "workgroup": 768, "workgroups_per_cu": 2}
+    r.Render()
+    a = r.DownloadRenderbuffer()
+    r.close()
+    monkeypatch.setenv("RT06_FORCE_BIG", "1")
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr())
+    assert not r.kernel_info()["lds_resident"]
+    r.Render()
+    b = r.DownloadRenderbuffer()
+    r.close()
+    assert a.tobytes() == b.tobytes()
