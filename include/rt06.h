@@ -85,7 +85,9 @@ enum {
     RT_MAT_METAL = 1,              /* MetalAbstract       cu_materials.cuh:68-96  param = fuzz          */
     RT_MAT_DIELECTRIC = 2,         /* DielectricAbstract  cu_materials.cuh:106-144 param = ior          */
     RT_MAT_LAMBERTIAN_CHECKER = 3, /* LambertianTexture   cu_materials.cuh:16-41  albedo/albedo2 = even/odd colour, param = 1/scale */
-    RT_MAT_DIFFUSE_LIGHT = 4       /* diffuse_light of "The Next Week" (not in the reference): emits albedo, never scatters    */
+    RT_MAT_DIFFUSE_LIGHT = 4,      /* diffuse_light of "The Next Week" (not in the reference): emits albedo, never scatters    */
+    RT_MAT_ISOTROPIC = 5           /* isotropic phase function of "The Next Week" (not in the reference): a SPHERE with this
+                                    * material is a constant_medium bounded by it; albedo = colour, param = density          */
 };
 typedef struct rt_material {
     float    albedo[3];
@@ -300,6 +302,9 @@ int rt_probe_sphere_index(int device, const rt_camera* cam, uint32_t width, uint
                           size_t n_spheres, const float* spheres, int32_t* out_index);
 /* raw uniforms of the counter-based RNG: keys n*2, n_draws each -> n*n_draws */
 int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t* keys, uint32_t n_draws, float* out);
+/* the deterministic fp32 log / sin / acos / atan2 of the extension materials (fn = 0..3; b is the second atan2
+ * argument, ignored otherwise): out[i] = f(a[i], b[i])                                                        */
+int rt_probe_math(int device, int fn, size_t n, const float* a, const float* b, float* out);
 
 /* Verification probes for the fast exact division of the streaming kernel (csrc/rt_fastdiv.hpp).
  * rt_probe_aabb_regular: boxes n*6, rays n*6, max_dist n -> the "regular ray" classification n, and

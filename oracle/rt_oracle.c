@@ -94,6 +94,78 @@ int orc_glm_near_zero(const float a[3]) { return near_zero(ld3(a)); }
 float orc_glm_length2(const float a[3]) { return length2_3(ld3(a)); }
 void orc_glm_lerp(const float a[3], const float b[3], float t, float out[3]) { st3(out, lerp3(ld3(a), ld3(b), t)); }
 float orc_glm_radians(float deg) { return radians(deg); }
+static inline uint32_t f2u(float x) { uint32_t u; memcpy(&u, &x, 4); return u; }
+static inline float u2f(uint32_t u) { float x; memcpy(&x, &u, 4); return x; }
+/* ---------------------------------------------------------------------------------------------
+ * Deterministic fp32 elementary functions for the extension materials (constant media, Perlin marble, sphere uv).
+ * The reference has none of these features; what matters here is that this CPU oracle and the GPU compute the SAME
+ * bits, which libm / ocml do not promise.  So: plain fp32 +, -, *, /, sqrt, floor and integer bit operations only,
+ * in one fixed order, no fused multiply-add (both sides build with -ffp-contract=off).  Accuracy is a few ulp.
+ * --------------------------------------------------------------------------------------------- */
+static float m_logf(float x) {  // x > 0, finite, normal
+    uint32_t ix = f2u(x);
+    int e = (int)(ix >> 23) - 127;
+    float m = u2f((ix & 0x007fffffu) | 0x3f800000u);  // [1, 2)
+    if (m > 0x1.6a09e6p+0f) { m = m * 0.5f; e += 1; }     // [sqrt(1/2), sqrt(2))
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = z * (0x1.555556p-1f + z * (0x1.99999ap-2f + z * (0x1.24924ap-2f + z * 0x1.c71c72p-3f)));  // 2/3, 2/5, 2/7, 2/9
+    float lm = s * (2.0f + p);                             // log(m) = 2 atanh(s)
+    float fe = (float)e;
+    return fe * 0x1.63p-1f + (fe * -0x1.bd0106p-13f + lm);  // e * ln2 in two words
+}
+static float m_sinf(float x) {  // |x| up to a few thousand
+    float kf = floorf(x * 0x1.45f306p-1f + 0.5f);          // nearest multiple of pi/2
+    int k = (int)kf;
+    float r = x - kf * 0x1.92p+0f;                          // pi/2 in three words (Cody-Waite)
+    r = r - kf * 0x1.fb4p-12f;
+    r = r - kf * 0x1.4442d2p-24f;
+    float r2 = r * r;
+    float sp = r + r * (r2 * (-0x1.555556p-3f + r2 * (0x1.111112p-7f + r2 * (-0x1.a01a02p-13f + r2 * 0x1.71de3ap-19f))));
+    float cp = 1.0f + r2 * (-0.5f + r2 * (0x1.555556p-5f + r2 * (-0x1.6c16c2p-10f + r2 * 0x1.a01a02p-16f)));
+    float v = (k & 1) ? cp : sp;
+    return (k & 2) ? -v : v;
+}
+static float m_asin_poly(float z) {  // (asin(x) - x) / x for z = x^2 <= 1/4, rational form of fdlibm's float asin
+    return z * (0x1.5554eap-3f + z * (-0x1.5e2774p-5f + z * -0x1.1ba6d6p-7f)) / (1.0f + z * -0x1.69cb5cp-1f);
+}
+static float m_acosf(float x) {  // |x| <= 1
+    float ax = x < 0.0f ? -x : x;
+    if (ax <= 0.5f) {
+        float r = m_asin_poly(x * x);
+        return 0x1.921fb6p+0f - (x + x * r);
+    }
+    float z = (1.0f - ax) * 0.5f;
+    float s = sqrtf(z);
+    float a = 2.0f * (s + s * m_asin_poly(z));             // acos(|x|)
+    return x < 0.0f ? 0x1.921fb6p+1f - a : a;
+}
+static float m_atan2f(float y, float x) {
+    float ax = x < 0.0f ? -x : x, ay = y < 0.0f ? -y : y;
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    int swap = ay > ax;
+    float t = swap ? ax / ay : ay / ax;                     // [0, 1]
+    float base = 0.0f;
+    if (t > 0x1.a8279ap-2f) { t = (t - 1.0f) / (t + 1.0f); base = 0x1.921fb6p-1f; }  // tan(pi/8): atan t = pi/4 + atan((t-1)/(t+1))
+    float z = t * t;
+    float p = z * (-0x1.555556p-2f + z * (0x1.99999ap-3f + z * (-0x1.24924ap-3f + z * (0x1.c71c72p-4f + z * (-0x1.745d18p-4f +
+              z * (0x1.3b13b2p-4f + z * (-0x1.111112p-4f + z * 0x1.e1e1e2p-5f)))))));
+    float a = base + (t + t * p);
+    if (swap) a = 0x1.921fb6p+0f - a;
+    if (x < 0.0f) a = 0x1.921fb6p+1f - a;
+    return y < 0.0f ? -a : a;
+}
+float orc_math_log(float x) { return m_logf(x); }
+float orc_math_sin(float x) { return m_sinf(x); }
+float orc_math_acos(float x) { return m_acosf(x); }
+float orc_math_atan2(float y, float x) { return m_atan2f(y, x); }
+/* fn: 0 log(a), 1 sin(a), 2 acos(a), 3 atan2(a, b) */
+void orc_math_batch(int fn, size_t n, const float* a, const float* b, float* out) {
+    for (size_t i = 0; i < n; i++)
+        out[i] = fn == 0 ? m_logf(a[i]) : fn == 1 ? m_sinf(a[i]) : fn == 2 ? m_acosf(a[i]) : m_atan2f(a[i], b[i]);
+}
+
 /* main/src/Renderer.cu:209-211: clamp(x,0,1) = min(max(x,0),1)
  * (glm/detail/func_common.inl:240-246), then sqrt */
 static inline v3 clamp01_sqrt(v3 a) {
@@ -224,11 +296,40 @@ static inline float sphere_closest_intersection(const ray_t* ray, v3 center, flo
 /* SphereHittable::ClosestIntersection (…/geometry/SphereHittable.cu:56-66) and
  * MovingSphereHittable::ClosestIntersection (:91-102) */
 static inline int prim_closest_intersection(const orc_world* w, int32_t idx, const ray_t* ray, rec_t* rec,
-                                            orc_counters* cnt) {
+                                            orc_counters* cnt, rng_t* g) {
     const orc_prim* p = &w->prims[idx];
     v3 center = ld3(p->c0);
     if (p->mat & ORC_PRIM_MOVING) center = mix3(ld3(p->c0), ld3(p->c1), ray->time);
     cnt->leaf_tests++;
+    const orc_material* pm = &w->materials[p->mat & ~ORC_PRIM_MOVING];
+    if (pm->type == 5) { /* RT_MAT_ISOTROPIC */
+        /* constant_medium::hit of "The Next Week" (extension; a sphere whose material is isotropic IS a constant medium
+         * bounded by that sphere, density = param), in the reference's conventions: the ray interval is [0, rec.distance)
+         * instead of [t_min, t_max], a tangent ray misses (SphereHittable.cuh:22).  ONE uniform is drawn per test that
+         * finds a non-empty interval inside the boundary, in traversal order. */
+        v3 oc = sub(ray->o, center);
+        float a = dot(ray->d, ray->d);
+        float hb = dot(ray->d, oc);
+        float c = dot(oc, oc) - p->radius * p->radius;
+        float d = hb * hb - a * c;
+        if (d <= 0) return 0;
+        d = sqrtf(d);
+        float t1 = (-hb - d) / a, t2 = (-hb + d) / a;
+        float t_in = t1 < 0.0f ? 0.0f : t1;
+        float t_out = t2 > rec->distance ? rec->distance : t2;
+        if (!(t_in < t_out)) return 0;
+        float ray_length = sqrtf(a);
+        float distance_inside = (t_out - t_in) * ray_length;
+        float hit_distance = (-1.0f / pm->param) * m_logf(rng_next(g));
+        if (hit_distance > distance_inside) return 0;
+        float tm = t_in + hit_distance / ray_length;
+        if (tm >= rec->distance) return 0;
+        rec->mat = p->mat & ~ORC_PRIM_MOVING;
+        rec->distance = tm;
+        rec->prim = idx;
+        rec->normal = V(1.0f, 0.0f, 0.0f);   /* arbitrary, as in the book: an isotropic scatter ignores it */
+        return 1;
+    }
     float t = sphere_closest_intersection(ray, center, p->radius);
     if (t >= rec->distance) return 0;
     rec->mat = p->mat & ~ORC_PRIM_MOVING;
@@ -261,9 +362,9 @@ static inline int quad_closest_intersection(const orc_world* w, int32_t qi, int3
     return 1;
 }
 
-static inline int any_prim_closest_intersection(const orc_world* w, int32_t idx, const ray_t* ray, rec_t* rec, orc_counters* cnt) {
+static inline int any_prim_closest_intersection(const orc_world* w, int32_t idx, const ray_t* ray, rec_t* rec, orc_counters* cnt, rng_t* g) {
     if ((uint32_t)idx >= w->n_prims) return quad_closest_intersection(w, idx - (int32_t)w->n_prims, idx, ray, rec, cnt);
-    return prim_closest_intersection(w, idx, ray, rec, cnt);
+    return prim_closest_intersection(w, idx, ray, rec, cnt, g);
 }
 
 static inline int node_box(const orc_node* n, const ray_t* ray, float maxd, float* dist, orc_counters* cnt) {
@@ -272,7 +373,7 @@ static inline int node_box(const orc_node* n, const ray_t* ray, float maxd, floa
 }
 
 /* BVH::ClosestIntersection, …/geometry/BVH.cu:54-106 (non-priority-queue branch) */
-static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err) {
+static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err, rng_t* g) {
     int32_t stack[ORC_STACK];
     int head = 0;
     const orc_node* nodes = w->nodes;
@@ -285,7 +386,7 @@ static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t*
         int32_t idx = stack[--head];
         const orc_node* node = &nodes[idx];
         if (node->left == -1) {
-            hit_any |= any_prim_closest_intersection(w, node->right, ray, rec, cnt);
+            hit_any |= any_prim_closest_intersection(w, node->right, ray, rec, cnt, g);
             continue;
         }
         float left_dist = ORC_MISS_DIST, right_dist = ORC_MISS_DIST;
@@ -305,36 +406,36 @@ static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t*
 }
 
 /* HittableList::ClosestIntersection, …/geometry/HittableList.cuh:21-34 */
-static int list_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt) {
+static int list_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, rng_t* g) {
     float d;
     cnt->box_tests++;
     if (!aabb_intersects(ld3(w->bounds_min), ld3(w->bounds_max), ray, rec->distance, &d)) return 0;
     int hit_any = 0;
     for (uint32_t i = 0; i < w->n_prims + w->n_quads; i++)
-        if (any_prim_closest_intersection(w, (int32_t)i, ray, rec, cnt)) hit_any = 1;
+        if (any_prim_closest_intersection(w, (int32_t)i, ray, rec, cnt, g)) hit_any = 1;
     return hit_any;
 }
 
 /* bvh_node::ClosestIntersection, …/geometry/bvh_node.cuh:19-24 (recursive, both
  * children, unordered).  ref >= 0 node, ref < 0 primitive (-ref-1). */
 static int tree_closest_intersection(const orc_world* w, int32_t ref, const ray_t* ray, rec_t* rec,
-                                     orc_counters* cnt, int depth, int* err) {
-    if (ref < 0) return prim_closest_intersection(w, -ref - 1, ray, rec, cnt);
+                                     orc_counters* cnt, int depth, int* err, rng_t* g) {
+    if (ref < 0) return prim_closest_intersection(w, -ref - 1, ray, rec, cnt, g);
     if (depth > 4096) { *err = 4; return 0; }
     const orc_node* n = &w->nodes[ref];
     float d;
     if (!node_box(n, ray, rec->distance, &d, cnt)) return 0;
-    int hit = tree_closest_intersection(w, n->left, ray, rec, cnt, depth + 1, err);
-    hit |= tree_closest_intersection(w, n->right, ray, rec, cnt, depth + 1, err);
+    int hit = tree_closest_intersection(w, n->left, ray, rec, cnt, depth + 1, err, g);
+    hit |= tree_closest_intersection(w, n->right, ray, rec, cnt, depth + 1, err, g);
     return hit;
 }
 
-static inline int world_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err) {
+static inline int world_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err, rng_t* g) {
     cnt->rays++;
     switch (w->kind) {
-    case 0: return bvh_closest_intersection(w, ray, rec, cnt, err);
-    case 1: return list_closest_intersection(w, ray, rec, cnt);
-    default: return tree_closest_intersection(w, w->root, ray, rec, cnt, 0, err);
+    case 0: return bvh_closest_intersection(w, ray, rec, cnt, err, g);
+    case 1: return list_closest_intersection(w, ray, rec, cnt, g);
+    default: return tree_closest_intersection(w, w->root, ray, rec, cnt, 0, err, g);
     }
 }
 
@@ -383,6 +484,11 @@ static int material_scatter(const orc_material* m, const ray_t* in_ray, const re
         v3 scatter_dir = add(refl, muls(rng_on_unit3(g), m->param));
         if (dot(scatter_dir, normal) < 0 || near_zero(scatter_dir)) return 0;
         out->o = ray_at(in_ray, rec->distance); out->d = scatter_dir; out->time = in_ray->time;
+        *attenuation = ld3(m->albedo);
+        return 1;
+    }
+    case 5: { /* isotropic phase function of "The Next Week" (extension): a uniformly random direction, always scatters */
+        out->o = ray_at(in_ray, rec->distance); out->d = rng_on_unit3(g); out->time = in_ray->time;
         *attenuation = ld3(m->albedo);
         return 1;
     }
@@ -480,7 +586,7 @@ static v3 sample_world(const orc_world* w, ray_t cur_ray, uint32_t max_depth, rn
     v3 accum_radiance = V(0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < max_depth; i++) {
         rec_t rec; rec.distance = ORC_MISS_DIST; rec.prim = -1; rec.mat = 0; rec.normal = V(0, 0, 0);
-        if (!world_closest_intersection(w, &cur_ray, &rec, cnt, err)) {
+        if (!world_closest_intersection(w, &cur_ray, &rec, cnt, err, g)) {
             v3 sky;
             if (w->background == 1) sky = ld3(w->background_color);
             else {
@@ -612,7 +718,8 @@ int orc_trace_batch(const orc_world* w, size_t n, const float* rays, int32_t* ou
     for (size_t i = 0; i < n; i++) {
         ray_t r = ld_ray7(rays + 7 * i);
         rec_t rec; rec.distance = ORC_MISS_DIST; rec.prim = -1; rec.mat = 0; rec.normal = V(0, 0, 0);
-        out_hit[i] = world_closest_intersection(w, &r, &rec, &cnt, &err);
+        rng_t g; rng_init(&g, 0u, (uint32_t)i, 0u, 0x7ACEu); /* only a constant medium draws from it */
+        out_hit[i] = world_closest_intersection(w, &r, &rec, &cnt, &err, &g);
         out_t[i] = rec.distance; out_prim[i] = rec.prim; st3(out_normal + 3 * i, rec.normal);
     }
     return err;

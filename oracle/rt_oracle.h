@@ -89,6 +89,13 @@ float  orc_glm_length2(const float a[3]);
 void   orc_glm_lerp(const float a[3], const float b[3], float t, float out[3]);
 float  orc_glm_radians(float deg);
 
+/* deterministic fp32 log / sin / acos / atan2 of the extension materials (not GLM, not libm: see rt_oracle.c) */
+float orc_math_log(float x);
+float orc_math_sin(float x);
+float orc_math_acos(float x);
+float orc_math_atan2(float y, float x);
+void  orc_math_batch(int fn, size_t n, const float* a, const float* b, float* out);
+
 /* ---- RNG ---- */
 void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 void   orc_rng_uniforms(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t stream,

@@ -93,6 +93,14 @@ class Scene:
         """diffuse_light of "The Next Week" (extension, not in the reference)."""
         return self.add_material(capi.MAT_DIFFUSE_LIGHT, emit)
 
+    def Isotropic(self, albedo, density):
+        """isotropic phase function of "The Next Week" (extension): a sphere made of it is a constant_medium of that density."""
+        return self.add_material(capi.MAT_ISOTROPIC, albedo, density)
+
+    def MakeConstantMedium(self, center, radius, density, albedo):
+        """constant_medium(sphere(center, radius), density, albedo) of "The Next Week" (extension, not in the reference)."""
+        return self.MakeSphere(center, radius, self.Isotropic(albedo, density))
+
     def MakeQuad(self, Q, u, v, mat):
         """quad(Q,u,v,mat) of "The Next Week" (extension, not in the reference)."""
         out = C.c_int32()
@@ -301,6 +309,15 @@ def probe_rng(seed, keys, n_draws, device=0):
     n = len(keys)
     out = np.zeros((n, n_draws), np.float32)
     check(lib().rt_probe_rng(device, seed, n, np.ascontiguousarray(keys, np.uint32), n_draws, out))
+    return out
+
+
+def probe_math(fn, a, b=None, device=0):
+    """rt_probe_math: fn 0 log, 1 sin, 2 acos, 3 atan2(a, b)."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(a if b is None else b, np.float32)
+    out = np.zeros_like(a)
+    check(lib().rt_probe_math(device, fn, len(a), a, b, out))
     return out
 
 

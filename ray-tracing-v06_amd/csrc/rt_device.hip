@@ -191,12 +191,15 @@ struct DeviceScene {
         // validate every index the kernels will follow: a bad index is a GPU fault, not an error code
         for (uint32_t i = 0; i < w->n_prims; i++)
             if ((w->prims[i].mat & ~RT_PRIM_MOVING) >= w->n_materials) return rt_fail(RT_ERR_INVALID, "primitive %u: material index out of range", i);
-        for (uint32_t i = 0; i < w->n_quads; i++)
+        for (uint32_t i = 0; i < w->n_quads; i++) {
             if (w->quads[i].mat >= w->n_materials) return rt_fail(RT_ERR_INVALID, "quad %u: material index out of range", i);
+            if (w->materials[w->quads[i].mat].type == RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "quad %u: a constant medium is bounded by a sphere (RT_MAT_ISOTROPIC on a quad)", i);
+        }
         extended = w->n_quads != 0 || w->background != 0;
         for (uint32_t i = 0; i < w->n_materials; i++) {
-            if (w->materials[i].type > RT_MAT_DIFFUSE_LIGHT) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
-            if (w->materials[i].type == RT_MAT_DIFFUSE_LIGHT) extended = true;
+            if (w->materials[i].type > RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
+            if (w->materials[i].type == RT_MAT_ISOTROPIC && !(w->materials[i].param > 0.0f)) return rt_fail(RT_ERR_INVALID, "material %u: a constant medium needs a density > 0", i);
+            if (w->materials[i].type >= RT_MAT_DIFFUSE_LIGHT) extended = true;
         }
         if (w->kind == RT_WORLD_BVH) {
             if (w->root < 0 || (uint32_t)w->root >= w->n_nodes) return rt_fail(RT_ERR_INVALID, "BVH root out of range");
@@ -606,7 +609,9 @@ __global__ void probe_trace_kernel(DeviceWorld w, size_t n, const float* rays, i
     r.o = ld3(rays + 7 * i); r.d = ld3(rays + 7 * i + 3); r.time = rays[7 * i + 6];
     HitRec rec;
     rec.distance = RT_MISS_DIST; rec.normal = mk3(0.0f); rec.prim = -1; rec.mat = 0;
-    hit[i] = world_closest_intersection(w, r, rec) ? 1 : 0;
+    Rng g;
+    g.init(0u, (uint32_t)i, 0u, 0x7ACEu);  // only a constant medium draws from it (same key as the oracle's probe)
+    hit[i] = world_closest_intersection(w, r, rec, &g) ? 1 : 0;
     t[i] = rec.distance; prim[i] = rec.prim;
     st3(normal + 3 * i, rec.normal);
 }
@@ -730,7 +735,7 @@ extern "C" int rt_probe_scatter(int device, uint64_t seed, size_t n, const rt_ma
         return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: null argument");
     if (n == 0) return RT_OK;
     for (size_t i = 0; i < n; i++)
-        if (mats[i].type > RT_MAT_DIFFUSE_LIGHT) return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: case %zu: unknown material type", i);
+        if (mats[i].type > RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "rt_probe_scatter: case %zu: unknown material type", i);
     int rc = select_device(device);
     if (rc != RT_OK) return rc;
     DevBuf m, r, d, nn, k, s, orr, a, dr;
@@ -808,6 +813,26 @@ extern "C" int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t*
     return RT_OK;
 }
 
+
+__global__ void probe_math_kernel(int fn, size_t n, const float* a, const float* b, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = fn == 0 ? rt_logf(a[i]) : fn == 1 ? rt_sinf(a[i]) : fn == 2 ? rt_acosf(a[i]) : rt_atan2f(a[i], b[i]);
+}
+extern "C" int rt_probe_math(int device, int fn, size_t n, const float* a, const float* b, float* out) {
+    if (!a || !b || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_math: null argument");
+    if (fn < 0 || fn > 3) return rt_fail(RT_ERR_INVALID, "rt_probe_math: unknown function %d", fn);
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf da, db, o;
+    UP(da, a, n * 4); UP(db, b, n * 4);
+    HIP_TRY(o.alloc(n * 4));
+    probe_math_kernel<<<PROBE_GRID(n)>>>(fn, n, da.as<float>(), db.as<float>(), o.as<float>());
+    FINISH();
+    DOWN(out, o, n * 4);
+    return RT_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // verification of rt_fastdiv.hpp

@@ -66,9 +66,43 @@ RT_HD float sphere_closest_intersection(const Ray& ray, f3 center, float radius)
 
 // SphereHittable::ClosestIntersection (SphereHittable.cu:56-66) /
 // MovingSphereHittable::ClosestIntersection (:91-102)
-RT_HD bool prim_closest_intersection(const rt_prim& p, int32_t idx, const Ray& ray, HitRec& rec) {
+// constant_medium::hit of "The Next Week" (extension, not in the reference): a sphere whose material is RT_MAT_ISOTROPIC
+// IS a constant medium bounded by that sphere, density = the material's param.  Reference conventions: the ray interval
+// is [0, rec.distance) instead of [t_min, t_max], a tangent ray misses (SphereHittable.cuh:22).  ONE uniform is drawn
+// per test that finds a non-empty interval inside the boundary, in traversal order.  Returns the hit distance or
+// RT_MISS_DIST.
+RT_HD float medium_sphere_intersection(const Ray& ray, f3 center, float radius, float density, float max_dist, Rng& rng) {
+    f3 oc = ray.o - center;
+    float a = dot(ray.d, ray.d);
+    float hb = dot(ray.d, oc);
+    float c = dot(oc, oc) - radius * radius;
+    float d = hb * hb - a * c;
+    if (d <= 0) return RT_MISS_DIST;
+    d = sqrtf(d);
+    float t1 = (-hb - d) / a, t2 = (-hb + d) / a;
+    float t_in = t1 < 0.0f ? 0.0f : t1;
+    float t_out = t2 > max_dist ? max_dist : t2;
+    if (!(t_in < t_out)) return RT_MISS_DIST;
+    float ray_length = sqrtf(a);
+    float distance_inside = (t_out - t_in) * ray_length;
+    float hit_distance = (-1.0f / density) * rt_logf(rng.next());
+    if (hit_distance > distance_inside) return RT_MISS_DIST;
+    return t_in + hit_distance / ray_length;
+}
+
+RT_HD bool prim_closest_intersection(const rt_prim& p, int32_t idx, const Ray& ray, HitRec& rec, const rt_material* mats, Rng* rng) {
     f3 center = mk3(p.c0[0], p.c0[1], p.c0[2]);
     if (p.mat & RT_PRIM_MOVING) center = mix(center, mk3(p.c1[0], p.c1[1], p.c1[2]), ray.time);
+    const rt_material& pm = mats[p.mat & ~RT_PRIM_MOVING];
+    if (pm.type == RT_MAT_ISOTROPIC) {
+        float tm = medium_sphere_intersection(ray, center, p.radius, pm.param, rec.distance, *rng);
+        if (tm >= rec.distance) return false;
+        rec.mat = p.mat & ~RT_PRIM_MOVING;
+        rec.distance = tm;
+        rec.prim = idx;
+        rec.normal = mk3(1.0f, 0.0f, 0.0f);  // arbitrary, as in the book: an isotropic scatter ignores it
+        return true;
+    }
     float t = sphere_closest_intersection(ray, center, p.radius);
     if (t >= rec.distance) return false;
     rec.mat = p.mat & ~RT_PRIM_MOVING;
@@ -97,13 +131,13 @@ RT_HD bool quad_closest_intersection(f3 Q, float D, f3 u, f3 v, f3 n, f3 w, uint
     return true;
 }
 
-__device__ inline bool any_prim_closest_intersection(const DeviceWorld& w, int32_t idx, const Ray& ray, HitRec& rec) {
+__device__ inline bool any_prim_closest_intersection(const DeviceWorld& w, int32_t idx, const Ray& ray, HitRec& rec, Rng* rng) {
     if ((uint32_t)idx >= w.n_prims) {
         const rt_quad& q = w.quads[(uint32_t)idx - w.n_prims];
         return quad_closest_intersection(mk3(q.Q[0], q.Q[1], q.Q[2]), q.D, mk3(q.u[0], q.u[1], q.u[2]), mk3(q.v[0], q.v[1], q.v[2]),
                                          mk3(q.normal[0], q.normal[1], q.normal[2]), mk3(q.w[0], q.w[1], q.w[2]), q.mat, idx, ray, rec);
     }
-    return prim_closest_intersection(w.prims[idx], idx, ray, rec);
+    return prim_closest_intersection(w.prims[idx], idx, ray, rec, w.mats, rng);
 }
 
 RT_HD bool node_box(const rt_bvh_node& n, const Ray& ray, float maxd, float& dist) {
@@ -113,7 +147,7 @@ RT_HD bool node_box(const rt_bvh_node& n, const Ray& ray, float maxd, float& dis
 // BVH::ClosestIntersection, rt_engine/geometry/BVH.cu:54-106 (the live, non-priority-queue branch):
 // root box first; pop; leaf -> primitive; inner -> test BOTH child boxes, order near-first, push far
 // then near iff dist < rec.distance; no re-check at pop.
-__device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+__device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
     int32_t stack[RT_MAX_STACK];
     int head = 0;
     float root_dist;
@@ -125,7 +159,7 @@ __device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray&
         const rt_bvh_node& node = w.nodes[idx];
         int32_t left_idx = node.left, right_idx = node.right;
         if (left_idx == -1) {
-            hit_any |= any_prim_closest_intersection(w, right_idx, ray, rec);
+            hit_any |= any_prim_closest_intersection(w, right_idx, ray, rec, rng);
             continue;
         }
         float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
@@ -142,19 +176,19 @@ __device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray&
 }
 
 // HittableList::ClosestIntersection, rt_engine/geometry/HittableList.cuh:21-34
-__device__ inline bool list_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+__device__ inline bool list_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
     float d;
     if (!aabb_intersects(w.bmin, w.bmax, ray, rec.distance, d)) return false;
     bool hit_any = false;
     for (uint32_t i = 0; i < w.n_prims + w.n_quads; i++)
-        if (any_prim_closest_intersection(w, (int32_t)i, ray, rec)) hit_any = true;
+        if (any_prim_closest_intersection(w, (int32_t)i, ray, rec, rng)) hit_any = true;
     return hit_any;
 }
 
 // bvh_node::ClosestIntersection, rt_engine/geometry/bvh_node.cuh:19-24, made iterative: the recursion
 // "own box, then left subtree, then right subtree" is a pre-order walk, i.e. pop / test / push right /
 // push left with the box test at visit time against the current rec.distance.
-__device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
+__device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
     int32_t stack[RT_MAX_STACK];
     int head = 0;
     stack[head++] = w.root;
@@ -163,7 +197,7 @@ __device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray
         int32_t ref = stack[--head];
         if (ref < 0) {
             int32_t pi = -ref - 1;
-            hit_any |= prim_closest_intersection(w.prims[pi], pi, ray, rec);
+            hit_any |= prim_closest_intersection(w.prims[pi], pi, ray, rec, w.mats, rng);
             continue;
         }
         const rt_bvh_node& n = w.nodes[ref];
@@ -175,10 +209,11 @@ __device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray
     return hit_any;
 }
 
-__device__ inline bool world_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec) {
-    if (w.kind == RT_WORLD_BVH) return bvh_closest_intersection(w, ray, rec);
-    if (w.kind == RT_WORLD_LIST) return list_closest_intersection(w, ray, rec);
-    return tree_closest_intersection(w, ray, rec);
+// rng: drawn from by constant media only (one uniform per test that enters the boundary)
+__device__ inline bool world_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
+    if (w.kind == RT_WORLD_BVH) return bvh_closest_intersection(w, ray, rec, rng);
+    if (w.kind == RT_WORLD_LIST) return list_closest_intersection(w, ray, rec, rng);
+    return tree_closest_intersection(w, ray, rec, rng);
 }
 
 // reflectance, rt_engine/shaders/cu_materials.cuh:99-104.  powf(1-cos,5) is evaluated as
@@ -216,6 +251,11 @@ RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRe
         if (near_zero(ray_dir)) return false;
         out.o = ray_at(in_ray, rec.distance); out.d = ray_dir; out.time = in_ray.time;
         attenuation = (m.type == RT_MAT_LAMBERTIAN) ? albedo : checker_value(albedo, albedo2, m.param, ray_at(in_ray, rec.distance));
+        return true;
+    }
+    if (m.type == RT_MAT_ISOTROPIC) {  // isotropic phase function of "The Next Week": a uniformly random direction, always scatters
+        out.o = ray_at(in_ray, rec.distance); out.d = rng_on_unit3(rng); out.time = in_ray.time;
+        attenuation = albedo;
         return true;
     }
     if (m.type == RT_MAT_METAL) {
@@ -274,7 +314,7 @@ __device__ inline f3 sample_world(const DeviceWorld& w, Ray cur_ray, uint32_t ma
     for (uint32_t i = 0; i < max_depth; i++) {
         HitRec rec;
         rec.distance = RT_MISS_DIST; rec.normal = mk3(0.0f); rec.prim = -1; rec.mat = 0;
-        if (!world_closest_intersection(w, cur_ray, rec)) {
+        if (!world_closest_intersection(w, cur_ray, rec, &rng)) {
             f3 sky;
             if (w.background == 1u) {
                 sky = w.background_color;

@@ -137,7 +137,8 @@ extern "C" void rt_scene_destroy(rt_scene* s) { delete s; }
 extern "C" int rt_scene_add_material(rt_scene* s, uint32_t type, const float albedo[3], float param,
                                      const float albedo2[3], int32_t* out_id) {
     if (!s || !albedo) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: null argument");
-    if (type > RT_MAT_DIFFUSE_LIGHT) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: unknown material type %u", type);
+    if (type > RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: unknown material type %u", type);
+    if (type == RT_MAT_ISOTROPIC && !(param > 0.0f)) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: a constant medium needs a density > 0");
     rt_material m;
     std::memset(&m, 0, sizeof(m));
     st3(m.albedo, ld3(albedo));

@@ -72,6 +72,67 @@ RT_HD f3 clamp01_sqrt(f3 a) {
     return mk3(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Deterministic fp32 elementary functions for the extension materials (constant media, Perlin marble, sphere uv).
+// The reference has none of these features; what matters here is that the CPU oracle and the GPU compute the SAME
+// bits, which libm / ocml do not promise.  So: plain fp32 +, -, *, /, sqrt, floor and integer bit operations only,
+// in one fixed order, no fused multiply-add (both sides build with -ffp-contract=off).  Accuracy is a few ulp.
+// ---------------------------------------------------------------------------------------------
+RT_HD float rt_logf(float x) {  // x > 0, finite, normal
+    uint32_t ix = __builtin_bit_cast(uint32_t, x);
+    int e = (int)(ix >> 23) - 127;
+    float m = __builtin_bit_cast(float, (ix & 0x007fffffu) | 0x3f800000u);  // [1, 2)
+    if (m > 0x1.6a09e6p+0f) { m = m * 0.5f; e += 1; }     // [sqrt(1/2), sqrt(2))
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = z * (0x1.555556p-1f + z * (0x1.99999ap-2f + z * (0x1.24924ap-2f + z * 0x1.c71c72p-3f)));  // 2/3, 2/5, 2/7, 2/9
+    float lm = s * (2.0f + p);                             // log(m) = 2 atanh(s)
+    float fe = (float)e;
+    return fe * 0x1.63p-1f + (fe * -0x1.bd0106p-13f + lm);  // e * ln2 in two words
+}
+RT_HD float rt_sinf(float x) {  // |x| up to a few thousand
+    float kf = floorf(x * 0x1.45f306p-1f + 0.5f);          // nearest multiple of pi/2
+    int k = (int)kf;
+    float r = x - kf * 0x1.92p+0f;                          // pi/2 in three words (Cody-Waite)
+    r = r - kf * 0x1.fb4p-12f;
+    r = r - kf * 0x1.4442d2p-24f;
+    float r2 = r * r;
+    float sp = r + r * (r2 * (-0x1.555556p-3f + r2 * (0x1.111112p-7f + r2 * (-0x1.a01a02p-13f + r2 * 0x1.71de3ap-19f))));
+    float cp = 1.0f + r2 * (-0.5f + r2 * (0x1.555556p-5f + r2 * (-0x1.6c16c2p-10f + r2 * 0x1.a01a02p-16f)));
+    float v = (k & 1) ? cp : sp;
+    return (k & 2) ? -v : v;
+}
+RT_HD float rt_asin_poly(float z) {  // (asin(x) - x) / x for z = x^2 <= 1/4, rational form of fdlibm's float asin
+    return z * (0x1.5554eap-3f + z * (-0x1.5e2774p-5f + z * -0x1.1ba6d6p-7f)) / (1.0f + z * -0x1.69cb5cp-1f);
+}
+RT_HD float rt_acosf(float x) {  // |x| <= 1
+    float ax = x < 0.0f ? -x : x;
+    if (ax <= 0.5f) {
+        float r = rt_asin_poly(x * x);
+        return 0x1.921fb6p+0f - (x + x * r);
+    }
+    float z = (1.0f - ax) * 0.5f;
+    float s = sqrtf(z);
+    float a = 2.0f * (s + s * rt_asin_poly(z));             // acos(|x|)
+    return x < 0.0f ? 0x1.921fb6p+1f - a : a;
+}
+RT_HD float rt_atan2f(float y, float x) {
+    float ax = x < 0.0f ? -x : x, ay = y < 0.0f ? -y : y;
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    bool swap = ay > ax;
+    float t = swap ? ax / ay : ay / ax;                     // [0, 1]
+    float base = 0.0f;
+    if (t > 0x1.a8279ap-2f) { t = (t - 1.0f) / (t + 1.0f); base = 0x1.921fb6p-1f; }  // tan(pi/8): atan t = pi/4 + atan((t-1)/(t+1))
+    float z = t * t;
+    float p = z * (-0x1.555556p-2f + z * (0x1.99999ap-3f + z * (-0x1.24924ap-3f + z * (0x1.c71c72p-4f + z * (-0x1.745d18p-4f +
+              z * (0x1.3b13b2p-4f + z * (-0x1.111112p-4f + z * 0x1.e1e1e2p-5f)))))));
+    float a = base + (t + t * p);
+    if (swap) a = 0x1.921fb6p+0f - a;
+    if (x < 0.0f) a = 0x1.921fb6p+1f - a;
+    return y < 0.0f ? -a : a;
+}
+
 // Ray, rt_engine/ray_data.cuh:8-15
 struct Ray {
     f3 o, d;

@@ -417,16 +417,22 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     uint32_t prim = (WORLD == RT_WORLD_LIST) ? code : code >> 1;
                     float4 sph = spheres[prim];
                     f3 center = mk3(sph.x, sph.y, sph.z);
+                    uint32_t sph_matbits = 0u;  // EXT: a sphere with an isotropic material is a constant medium
                     if (WORLD == RT_WORLD_LIST) {
                         float4 ex = extra[prim];
                         const uint32_t moving = (__float_as_uint(ex.w) >> 28) & 1u;
                         code = prim * 2u + moving;
                         if (moving) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
-                    } else if (code & 1u) {
+                    } else if (EXT || (code & 1u)) {
                         float4 ex = extra[prim];
-                        center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                        if (code & 1u) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                        sph_matbits = __float_as_uint(ex.w);
                     }
-                    float t = sphere_closest_intersection(ray, center, sph.w);
+                    float t;
+                    if (EXT && (sph_matbits >> 29) == RT_MAT_ISOTROPIC)
+                        t = medium_sphere_intersection(ray, center, sph.w, mats16[sph_matbits & RT_MAT_INDEX_MASK].w, rec_t, rng);
+                    else
+                        t = sphere_closest_intersection(ray, center, sph.w);
                     if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
                         rec_t = t;
                         rec_code = (int32_t)code;
@@ -526,7 +532,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     RT_PT(11);
                     f3 on_unit = rng_on_unit3(rng);
                     RT_PT(12);
-                    if (mtype == RT_MAT_METAL) {
+                    if (EXT && mtype == RT_MAT_ISOTROPIC) {
+                        scatter_dir = on_unit;   // isotropic phase function: any direction, never absorbed
+                    } else if (mtype == RT_MAT_METAL) {
                         scatter_dir = reflect(ray.d, normal) + on_unit * mparam;
                         scattered_ok = !(dot(scatter_dir, normal) < 0 || near_zero(scatter_dir));
                     } else {

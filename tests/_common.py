@@ -66,17 +66,17 @@ def config_scene(p, which, seed=1984):
     return getattr(p.Scene, which)() if which in ("three_spheres", "cornell_box") else getattr(p.Scene, which)(seed)
 
 
-def random_mixed_scene(p, rng, n_spheres, n_quads, builder, background=None, lights=True):
-    """The same random spheres + quads (+ lights) through the product vocabulary and the oracle's arrays."""
+def random_mixed_scene(p, rng, n_spheres, n_quads, builder, background=None, lights=True, media=False):
+    """The same random spheres + quads (+ lights, + constant media) through the product vocabulary and the oracle's arrays."""
     s = p.Scene()
-    n_mats = 6
+    n_mats = 8 if media else 6
     mats = np.zeros(n_mats, dtype=O.MAT_DT)
     for i in range(n_mats):
         albedo = rng.random(3, dtype=np.float32)
-        mtype = [0, 1, 2, 0, 1, 4][i] if lights else [0, 1, 2, 0, 1, 0][i]
+        mtype = ([0, 1, 2, 0, 1, 4, 5, 5][i] if lights else [0, 1, 2, 0, 1, 0, 5, 5][i])
         if mtype == 4:
             albedo = (albedo * np.float32(6.0)).astype(np.float32)
-        param = np.float32([0.0, 0.3, 1.5, 0.0, 0.0, 0.0][i])
+        param = np.float32([0.0, 0.3, 1.5, 0.0, 0.0, 0.0, 0.8, 0.05][i])
         s.add_material(mtype, albedo, float(param))
         mats[i] = (albedo, param, (0, 0, 0), mtype)
     prims = np.zeros(n_spheres, dtype=O.PRIM_DT)
@@ -86,6 +86,8 @@ def random_mixed_scene(p, rng, n_spheres, n_quads, builder, background=None, lig
         c1 = (c0 + rng.random(3, dtype=np.float32) * np.float32(0.5)).astype(np.float32) if moving else c0
         rad = np.float32(0.2 + rng.random() * 0.8)
         m = int(rng.integers(0, n_mats))
+        if m == 7:
+            rad = np.float32(rad * 6)   # the thin medium is a large ball of haze
         (s.MakeMovingSphere(c0, c1, rad, m) if moving else s.MakeSphere(c0, rad, m))
         prims[i] = (c0, rad, c1, m | (0x80000000 if moving else 0))
     quads = np.zeros(n_quads, dtype=O.QUAD_DT)
@@ -95,7 +97,7 @@ def random_mixed_scene(p, rng, n_spheres, n_quads, builder, background=None, lig
             u = np.float32([rng.random() * 4 + 0.5, 0, 0]); v = np.float32([0, 0, rng.random() * 4 + 0.5])
         else:
             u = (rng.standard_normal(3) * 2).astype(np.float32); v = (rng.standard_normal(3) * 2).astype(np.float32)
-        m = int(rng.integers(0, n_mats))
+        m = int(rng.integers(0, 6))   # a quad never bounds a medium
         s.MakeQuad(Q, u, v, m)
         quads[i]["Q"], quads[i]["u"], quads[i]["v"], quads[i]["mat"] = Q, u, v, m
     if background is not None:

@@ -84,6 +84,7 @@ def lib():
     L.orc_glm_lerp.argtypes = [v3, v3, C.c_float, v3]
     L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
     L.orc_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
+    L.orc_math_batch.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
     L.orc_aabb_batch.argtypes = [C.c_size_t, f32p, f32p, f32p, i32p, f32p]
     L.orc_sphere_batch.argtypes = [C.c_size_t, f32p, f32p, f32p]
     L.orc_trace_batch.argtypes = [C.POINTER(World), C.c_size_t, f32p, i32p, f32p, i32p, f32p]

@@ -163,3 +163,92 @@ def test_cornell_box_sharded_over_four_ranks_is_the_same_image(p):
     last.assemble(torch.cat(shards).data_ptr(), image.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert image.cpu().numpy().reshape(H, W, 4).tobytes() == ref.tobytes()
+
+
+def _math_inputs():
+    rng = np.random.default_rng(31)
+    u = ((rng.integers(0, 1 << 24, 1 << 16) + 1) * 2.0 ** -24).astype(np.float32)      # every uniform the RNG can produce is of this form
+    xs = np.concatenate([(rng.random(1 << 16) * 4000 - 2000), [0.0, -0.0, 1e-8, 3.14159274, 1.57079637]]).astype(np.float32)
+    xc = np.concatenate([(rng.random(1 << 16) * 2 - 1), [-1.0, 1.0, 0.0, 0.5, -0.5]]).astype(np.float32)
+    ya = np.concatenate([rng.standard_normal(1 << 16), [0.0, 0.0, 1.0, -1.0, 0.0]]).astype(np.float32)
+    xa = np.concatenate([rng.standard_normal(1 << 16), [1.0, -1.0, 0.0, 0.0, 0.0]]).astype(np.float32)
+    return u, xs, xc, ya, xa
+
+
+def test_extension_math_is_bit_identical_on_cpu_and_gpu(p):
+    """log / sin / acos / atan2 of the extension materials: own fp32 routines, same bits in the oracle and on the GPU."""
+    u, xs, xc, ya, xa = _math_inputs()
+    for fn, a, b in ((0, u, u), (1, xs, xs), (2, xc, xc), (3, ya, xa)):
+        exp = np.zeros_like(a)
+        O.lib().orc_math_batch(fn, len(a), a, b, exp)
+        got = p.api.probe_math(fn, a, b)
+        assert bits_equal(got, exp), f"fn {fn}: " + mismatch_report(got, exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# constant media (constant_medium + isotropic of "The Next Week"): the second widening step, parity unpinned as above
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("builder", [0, 1, 2, 3])
+def test_closest_intersection_through_constant_media(p, builder):
+    """A medium test draws a uniform (free path ~ -log(u) / density) in traversal order: hit, t, primitive must match."""
+    rng = np.random.default_rng(170 + builder)
+    s, _ = random_mixed_scene(p, rng, 40, 20, builder, media=True)
+    w = s.getWorldPtr()
+    n = 16384
+    rays = random_rays(rng, n, spread=7.0)
+    rays[: n // 2, 3:6] = -rays[: n // 2, 0:3] + rng.standard_normal((n // 2, 3)).astype(np.float32)
+    hit, t, prim, nrm = p.api.probe_trace(w, rays)
+    ow = as_oracle_world(w)
+    ehit = np.zeros(n, np.int32); et = np.zeros(n, np.float32); eprim = np.zeros(n, np.int32); en = np.zeros((n, 3), np.float32)
+    assert O.lib().orc_trace_batch(C.byref(ow), n, rays, ehit, et, eprim, en) == 0
+    assert np.array_equal(hit, ehit) and np.array_equal(prim, eprim), f"{(prim != eprim).sum()} primitive indices differ"
+    assert bits_equal(t, et), mismatch_report(t, et)
+    assert bits_equal(nrm, en), mismatch_report(nrm, en)
+    mats = s.arrays()[2]
+    prims = s.arrays()[1]
+    is_medium = mats["type"][prims["mat"] & 0x7fffffff] == 5
+    hit_medium = is_medium[np.clip(prim, 0, len(prims) - 1)] & (hit != 0) & (prim < len(prims))
+    assert hit_medium.mean() > 0.02   # the media do stop rays
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_random_scenes_with_media_render_bit_exact(p, seed):
+    rng = np.random.default_rng(7000 + seed)
+    builder = int(rng.integers(0, 4))
+    bg = None if rng.random() < 0.5 else tuple(float(x) for x in rng.random(3) * 0.3)
+    ns, nq = int(rng.integers(4, 40)), int(rng.integers(0, 20))
+    s, _ = random_mixed_scene(p, rng, ns, nq, builder, background=bg, media=True)
+    W, H = int(rng.integers(17, 97)), int(rng.integers(9, 65))
+    spp, depth = int(rng.integers(1, 24)), int(rng.choice([1, 2, 5, 50]))
+    eye = ((rng.random(3) * 2 - 1) * np.array([9, 4, 9])).astype(np.float32)
+    cam = p.MotionBlurCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H, 0.0, 1.0)
+    img, ref = _render_both(p, s, cam, W, H, spp, depth=depth)
+    tag = f"seed {seed} builder {builder} bg {bg} {W}x{H}x{spp} depth {depth} spheres {ns} quads {nq}: "
+    assert np.array_equal(np.isnan(img), np.isnan(ref)), tag
+    if builder == 3:
+        assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED * max(1.0, float(np.nanmax(ref))), tag
+    else:
+        assert bits_equal(img, ref), tag + mismatch_report(img, ref)
+
+
+def test_camera_inside_a_global_fog(p):
+    """The Book-2 final scene wraps everything in a thin constant medium (radius 5000, density 1e-4): the camera is INSIDE it."""
+    s = p.Scene()
+    ground = s.Lambertian((0.48, 0.83, 0.53))
+    s.MakeSphere((0, -1000, 0), 1000.0, ground)
+    s.MakeSphere((0, 1, 0), 1.0, s.Dielectric((1, 1, 1), 1.5))
+    s.MakeConstantMedium((0, 1, 0), 1.0, 0.2, (0.2, 0.4, 0.9))          # subsurface: a medium inside the glass ball
+    s.MakeSphere((2.5, 1, 0.5), 1.0, s.Metal((0.8, 0.8, 0.9), 0.5))
+    s.MakeQuad((-2, 4, -2), (3, 0, 0), (0, 0, 3), s.DiffuseLight((7, 7, 7)))
+    s.MakeConstantMedium((0, 0, 0), 5000.0, 0.0001, (1, 1, 1))
+    s.set_background((0, 0, 0))
+    s.BuildBVH_TopDown()
+    W, H, spp = 120, 80, 16
+    cam = p.PinholeCamera((6, 2.5, 7), (0, 1, 0), (0, 1, 0), 35.0, W / H)
+    for variant in (0, 1, 2):
+        img, ref = _render_both(p, s, cam, W, H, spp, variant=variant)
+        if variant == 1:
+            assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED
+        else:
+            assert bits_equal(img, ref), f"variant {variant}: " + mismatch_report(img, ref)
+    assert ref[..., :3].max() > 0.5 and ref[..., :3].mean() > 0.01
