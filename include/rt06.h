@@ -86,8 +86,12 @@ enum {
     RT_MAT_DIELECTRIC = 2,         /* DielectricAbstract  cu_materials.cuh:106-144 param = ior          */
     RT_MAT_LAMBERTIAN_CHECKER = 3, /* LambertianTexture   cu_materials.cuh:16-41  albedo/albedo2 = even/odd colour, param = 1/scale */
     RT_MAT_DIFFUSE_LIGHT = 4,      /* diffuse_light of "The Next Week" (not in the reference): emits albedo, never scatters    */
-    RT_MAT_ISOTROPIC = 5           /* isotropic phase function of "The Next Week" (not in the reference): a SPHERE with this
+    RT_MAT_ISOTROPIC = 5,          /* isotropic phase function of "The Next Week" (not in the reference): a SPHERE with this
                                     * material is a constant_medium bounded by it; albedo = colour, param = density          */
+    RT_MAT_LAMBERTIAN_NOISE = 6,   /* lambertian(noise_texture(scale)) of "The Next Week" (not in the reference): colour =
+                                    * albedo * (1 + sin(param * p.z + 10 * turb(p, 7))) over the world's Perlin tables        */
+    RT_MAT_LAMBERTIAN_IMAGE = 7    /* lambertian(image_texture) of "The Next Week" on a sphere: colour = the world's RGB8
+                                    * image at the sphere's (u, v)                                                             */
 };
 typedef struct rt_material {
     float    albedo[3];
@@ -103,6 +107,12 @@ enum {
 };
 /* The `const Hittable* d_world_ptr` argument of Renderer::MakeRenderer,
  * resolved to flat host arrays.  Borrowed during rt_renderer_create only.   */
+/* Perlin noise tables of "The Next Week" (perlin::randvec, perm_x/y/z), generated by rt_scene_set_perlin; 6144 B */
+typedef struct rt_perlin {
+    float   randvec[256][3];
+    int32_t perm[3][256];
+} rt_perlin;
+
 typedef struct rt_world_flat {
     uint32_t kind;         /* RT_WORLD_*                                              */
     int32_t  root;         /* root node index (BVH: last node; NODE_TREE: child ref)  */
@@ -120,8 +130,12 @@ typedef struct rt_world_flat {
     uint32_t n_quads;
     uint32_t background;         /* 0: the reference's sky gradient (Renderer.cu:150-151); 1: background_color */
     float    background_color[3];
+    uint32_t image_width;        /* RT_MAT_LAMBERTIAN_IMAGE: one RGB8 image per world, row 0 = top (as stb_image loads it) */
+    const rt_perlin* perlin;     /* RT_MAT_LAMBERTIAN_NOISE: the world's noise tables, or NULL                            */
+    const uint8_t*   image;      /* image_width * image_height * 3 bytes, or NULL                                         */
+    uint32_t image_height;
     uint32_t reserved;
-} rt_world_flat;
+} rt_world_flat;                 /* 128 B */
 
 enum {
     RT_CAM_PINHOLE = 0,  /* PinholeCamera     cu_Cameras.cuh:12-31 */
@@ -176,6 +190,11 @@ int rt_scene_prim_bounds(const rt_scene* s, int32_t prim, float out_min[3], floa
 int rt_scene_add_quad(rt_scene* s, const float Q[3], const float u[3], const float v[3], int32_t mat, int32_t* out_quad);
 /* camera::background of "The Next Week": mode 0 = the reference's sky gradient, 1 = constant colour       */
 int rt_scene_set_background(rt_scene* s, uint32_t mode, const float color[3]);
+/* perlin::perlin() of "The Next Week": 256 random unit vectors + three Fisher-Yates permutations, drawn from the
+ * build's host stream (rt_host_uniforms, stream id 0x9E81) with this seed                                  */
+int rt_scene_set_perlin(rt_scene* s, uint64_t seed);
+/* the image of image_texture (the book loads earthmap.jpg; any RGB8 array here), copied                     */
+int rt_scene_set_image(rt_scene* s, uint32_t width, uint32_t height, const uint8_t* rgb);
 
 /* BVH_Handle::Factory::BuildBVH_TopDown -> _build_bvh_rec1 (BVH.cu:166-210):
  * median split on the longest axis, leaf size 1, post-order numbering, root =

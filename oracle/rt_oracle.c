@@ -461,22 +461,75 @@ static inline v3 checker_value(const orc_material* m, v3 pos) {
     return (sum % 2 == 0) ? ld3(m->albedo) : ld3(m->albedo2);
 }
 
+/* perlin::noise / perlin_interp / turb, noise_texture::value, sphere::get_sphere_uv, image_texture::value of "The Next
+ * Week" (extension, not in the reference): fp32, one fixed evaluation order, own sin / acos / atan2 (m_*). */
+static float perlin_noise(const orc_perlin* t, v3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = (u * u) * (3.0f - 2.0f * u), vv = (v * v) * (3.0f - 2.0f * v), ww = (w * w) * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = t->perm[0][(i + di) & 255] ^ t->perm[1][(j + dj) & 255] ^ t->perm[2][(k + dk) & 255];
+                const float* c = t->randvec[idx];
+                float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+                float d = c[0] * wx + c[1] * wy + c[2] * wz;
+                float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+                accum += ((wi * wj) * wk) * d;
+            }
+    return accum;
+}
+static float perlin_turb(const orc_perlin* t, v3 p, int depth) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(t, p);
+        weight *= 0.5f;
+        p = muls(p, 2.0f);
+    }
+    return fabsf(accum);
+}
+static v3 noise_value(const orc_perlin* t, v3 albedo, float scale, v3 p) {
+    return muls(albedo, 1.0f + m_sinf(scale * p.z + 10.0f * perlin_turb(t, p, 7)));
+}
+static v3 image_value(const uint8_t* image, uint32_t width, uint32_t height, v3 n) {
+    float cy = -n.y;
+    cy = cy < -1.0f ? -1.0f : (cy > 1.0f ? 1.0f : cy);
+    float theta = m_acosf(cy);
+    float phi = m_atan2f(-n.z, n.x) + 0x1.921fb6p+1f;
+    float u = phi / 0x1.921fb6p+2f, v = theta / 0x1.921fb6p+1f;
+    u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    v = 1.0f - v;
+    int i = (int)(u * (float)width), j = (int)(v * (float)height);
+    if (i > (int)width - 1) i = (int)width - 1;
+    if (j > (int)height - 1) j = (int)height - 1;
+    const uint8_t* px = image + ((size_t)j * width + (size_t)i) * 3u;
+    return V((float)px[0] * 0x1.010102p-8f, (float)px[1] * 0x1.010102p-8f, (float)px[2] * 0x1.010102p-8f);
+}
+
 /* Material::Scatter for the four material classes:
  *  LambertianAbstract  …/shaders/cu_materials.cuh:52-64
  *  MetalAbstract       :77-95
  *  DielectricAbstract  :115-143
  *  LambertianTexture   :27-40 */
 static int material_scatter(const orc_material* m, const ray_t* in_ray, const rec_t* rec, rng_t* g,
-                            ray_t* out, v3* attenuation) {
+                            ray_t* out, v3* attenuation, const orc_world* w) {
     v3 normal = rec->normal;
     if (m->type == 4) return 0; /* diffuse_light of "The Next Week": emits (material_emitted), never scatters */
     switch (m->type) {
     case 0:
-    case 3: {
+    case 3:
+    case 6:   /* lambertian(noise_texture) */
+    case 7: { /* lambertian(image_texture) */
         v3 ray_dir = add(normal, rng_on_unit3(g));
         if (near_zero(ray_dir)) return 0;
         out->o = ray_at(in_ray, rec->distance); out->d = ray_dir; out->time = in_ray->time;
-        *attenuation = (m->type == 0) ? ld3(m->albedo) : checker_value(m, ray_at(in_ray, rec->distance));
+        if (m->type == 0) *attenuation = ld3(m->albedo);
+        else if (m->type == 3) *attenuation = checker_value(m, ray_at(in_ray, rec->distance));
+        else if (m->type == 6) *attenuation = noise_value(w->perlin, ld3(m->albedo), m->param, ray_at(in_ray, rec->distance));
+        else *attenuation = image_value(w->image, w->image_width, w->image_height, normal);
         return 1;
     }
     case 1: {
@@ -599,7 +652,7 @@ static v3 sample_world(const orc_world* w, ray_t cur_ray, uint32_t max_depth, rn
         const orc_material* m = &w->materials[rec.mat];
         if (m->type == 4) accum_radiance = add(accum_radiance, mul(accum_attenuation, ld3(m->albedo)));
         ray_t scattered; v3 attenuation;
-        if (!material_scatter(m, &cur_ray, &rec, g, &scattered, &attenuation))
+        if (!material_scatter(m, &cur_ray, &rec, g, &scattered, &attenuation, w))
             return accum_radiance;
         accum_attenuation = mul(accum_attenuation, attenuation);
         cur_ray = scattered;
@@ -733,7 +786,7 @@ void orc_scatter_batch(uint64_t seed, size_t n, const orc_material* mats, const 
         rng_t g; rng_init(&g, seed, keys[2 * i], keys[2 * i + 1], 0u);
         ray_t out; out.o = V(0, 0, 0); out.d = V(0, 0, 0); out.time = 0.0f;
         v3 att = V(0, 0, 0);
-        out_scattered[i] = material_scatter(&mats[i], &in, &rec, &g, &out, &att);
+        out_scattered[i] = material_scatter(&mats[i], &in, &rec, &g, &out, &att, NULL);
         st_ray7(out_rays + 7 * i, &out); st3(out_atten + 3 * i, att); out_draws[i] = g.draws;
     }
 }
@@ -798,6 +851,8 @@ struct orc_scene {
     uint32_t background; float background_color[3];
     orc_material* mats; size_t n_mats;
     orc_node* nodes; size_t n_nodes, cap_nodes;
+    orc_perlin* perlin;
+    uint8_t* image; uint32_t image_w, image_h;
     orc_world world;
 };
 
@@ -1145,7 +1200,38 @@ orc_scene* orc_scene_cornell_box(void) {
     return orc_scene_from_arrays_ext(0, NULL, n, quads, 4, mats, 0, 1, black);
 }
 void orc_scene_world(const orc_scene* s, orc_world* out) { *out = s->world; }
+/* perlin::perlin() of "The Next Week": randvec[i] = unit_vector(random(-1,1)^3); perm = identity shuffled by
+ * `for i = n-1 .. 1: swap(p[i], p[random_int(0, i)])`, three times; uniforms from the host stream, id 0x9E81 */
+void orc_scene_set_perlin(orc_scene* s, uint64_t seed) {
+    rng_t g; rng_init(&g, seed, 0u, 0u, 0x9E81u);
+    if (!s->perlin) s->perlin = (orc_perlin*)malloc(sizeof(orc_perlin));
+    orc_perlin* t = s->perlin;
+    for (int i = 0; i < 256; i++) {
+        v3 v;
+        v.x = rng_next(&g) * 2.0f - 1.0f;
+        v.y = rng_next(&g) * 2.0f - 1.0f;
+        v.z = rng_next(&g) * 2.0f - 1.0f;
+        if (near_zero(v)) v = V(1.0f, 0.0f, 0.0f);
+        st3(t->randvec[i], normalize(v));
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < 256; i++) t->perm[k][i] = i;
+        for (int i = 255; i > 0; i--) {
+            int target = (int)(rng_next(&g) * (float)(i + 1));
+            if (target > i) target = i;
+            int32_t tmp = t->perm[k][i]; t->perm[k][i] = t->perm[k][target]; t->perm[k][target] = tmp;
+        }
+    }
+    s->world.perlin = t;
+}
+void orc_scene_set_image(orc_scene* s, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    free(s->image);
+    s->image = (uint8_t*)malloc((size_t)width * height * 3);
+    memcpy(s->image, rgb, (size_t)width * height * 3);
+    s->image_w = width; s->image_h = height;
+    s->world.image = s->image; s->world.image_width = width; s->world.image_height = height;
+}
 void orc_scene_free(orc_scene* s) {
     if (!s) return;
-    free(s->prims); free(s->quads); free(s->mats); free(s->nodes); free(s);
+    free(s->prims); free(s->quads); free(s->mats); free(s->nodes); free(s->perlin); free(s->image); free(s);
 }

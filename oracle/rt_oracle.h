@@ -56,8 +56,15 @@ typedef struct {
     const orc_quad* quads; uint32_t n_quads;
     uint32_t background;        /* 0: the reference's sky gradient (Renderer.cu:150-151); 1: constant background_color */
     float background_color[3];
+    /* second extension (constant media need nothing here): Perlin tables and one RGB8 image for the textured materials */
+    uint32_t image_width;
+    const struct orc_perlin* perlin;
+    const uint8_t* image;
+    uint32_t image_height;
     uint32_t reserved;
 } orc_world;
+/* perlin::randvec / perm_x,y,z of "The Next Week" */
+typedef struct orc_perlin { float randvec[256][3]; int32_t perm[3][256]; } orc_perlin;
 typedef struct {
     uint32_t type; float o[3], u[3], v[3], w[3];
     float viewport_width, viewport_height, lens_radius, focus_dist, t0, t1;
@@ -153,6 +160,9 @@ orc_scene* orc_scene_from_arrays_ext(size_t n_prims, const orc_prim* prims, size
 /* the Cornell box of "The Next Week" (BASELINE.json configs[3]): 5 walls, a light, two rotated boxes as 12 quads */
 orc_scene* orc_scene_cornell_box(void);
 void orc_scene_world(const orc_scene* s, orc_world* out);
+/* perlin::perlin() from the build's host stream (id 0x9E81) / the image of image_texture, attached to a scene */
+void orc_scene_set_perlin(orc_scene* s, uint64_t seed);
+void orc_scene_set_image(orc_scene* s, uint32_t width, uint32_t height, const uint8_t* rgb);
 void orc_scene_free(orc_scene* s);
 
 #ifdef __cplusplus

@@ -101,6 +101,26 @@ class Scene:
         """constant_medium(sphere(center, radius), density, albedo) of "The Next Week" (extension, not in the reference)."""
         return self.MakeSphere(center, radius, self.Isotropic(albedo, density))
 
+    def set_perlin(self, seed=1984):
+        """perlin::perlin() of "The Next Week" (extension): the world's noise tables."""
+        check(lib().rt_scene_set_perlin(self.h, seed))
+        return self
+
+    def NoiseTexture(self, scale, albedo=(0.5, 0.5, 0.5)):
+        """lambertian(noise_texture(scale)) of "The Next Week" (extension); needs set_perlin()."""
+        return self.add_material(capi.MAT_LAMBERTIAN_NOISE, albedo, scale)
+
+    def set_image(self, rgb):
+        """The image of image_texture (extension): uint8 array [H][W][3], row 0 = top."""
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        check(lib().rt_scene_set_image(self.h, rgb.shape[1], rgb.shape[0], rgb.ctypes.data))
+        return self
+
+    def ImageTexture(self):
+        """lambertian(image_texture) of "The Next Week" on spheres (extension); needs set_image()."""
+        return self.add_material(capi.MAT_LAMBERTIAN_IMAGE, (1, 1, 1))
+
     def MakeQuad(self, Q, u, v, mat):
         """quad(Q,u,v,mat) of "The Next Week" (extension, not in the reference)."""
         out = C.c_int32()

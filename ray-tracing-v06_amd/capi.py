@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(CSRC_DIR, "librt06.so")
 
 RT_OK = 0
 RT_PRIM_MOVING = 0x80000000
-MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LAMBERTIAN_CHECKER, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4, 5
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_LAMBERTIAN_CHECKER, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC, MAT_LAMBERTIAN_NOISE, MAT_LAMBERTIAN_IMAGE = 0, 1, 2, 3, 4, 5, 6, 7
 WORLD_BVH, WORLD_LIST, WORLD_NODE_TREE = 0, 1, 2
 CAM_PINHOLE, CAM_DEFOCUS, CAM_MOTION = 0, 1, 2
 
@@ -37,7 +37,8 @@ class WorldFlat(C.Structure):
                 ("bounds_min", vec3), ("bounds_max", vec3),
                 ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p),
                 ("quads", C.c_void_p), ("n_quads", C.c_uint32), ("background", C.c_uint32),
-                ("background_color", vec3), ("reserved", C.c_uint32)]
+                ("background_color", vec3), ("image_width", C.c_uint32),
+                ("perlin", C.c_void_p), ("image", C.c_void_p), ("image_height", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -62,7 +63,7 @@ class RtError(RuntimeError):
 SYMBOLS = [
     "rt_last_error", "rt_camera_pinhole", "rt_camera_defocus", "rt_camera_motion",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_material", "rt_scene_add_sphere",
-    "rt_scene_add_moving_sphere", "rt_scene_add_quad", "rt_scene_set_background", "rt_scene_cornell_box", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
+    "rt_scene_add_moving_sphere", "rt_scene_add_quad", "rt_scene_set_background", "rt_scene_set_perlin", "rt_scene_set_image", "rt_scene_cornell_box", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
     "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list", "rt_scene_add_bvh_node",
     "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
     "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
@@ -127,6 +128,8 @@ def lib():
     L.rt_scene_add_moving_sphere.argtypes = [C.c_void_p, vec3, vec3, C.c_float, C.c_int32, P(C.c_int32)]
     L.rt_scene_add_quad.argtypes = [C.c_void_p, vec3, vec3, vec3, C.c_int32, P(C.c_int32)]
     L.rt_scene_set_background.argtypes = [C.c_void_p, C.c_uint32, vec3]
+    L.rt_scene_set_perlin.argtypes = [C.c_void_p, C.c_uint64]
+    L.rt_scene_set_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.rt_scene_cornell_box.argtypes = [P(C.c_void_p)]
     L.rt_scene_prim_bounds.argtypes = [C.c_void_p, C.c_int32, vec3, vec3]
     for n in ("rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah", "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list"):

@@ -64,7 +64,7 @@ static void write_wide_node(uint4* blob, bool big, uint32_t index, const float l
 }
 
 struct DeviceScene {
-    DevBuf nodes, prims, mats, blob, quads;
+    DevBuf nodes, prims, mats, blob, quads, perlin, image;
     bool extended = false;  // quads, an emissive material or a constant background: beyond the reference's feature set
     DeviceWorld dw{};
     PackedSceneRef packed{};  // valid when has_packed
@@ -174,6 +174,7 @@ struct DeviceScene {
         packed.n_prims = w->n_prims;
         packed.stack_cap = (true_stack ? true_stack : 1u) + 1u;  // + the sentinel entry at the bottom (RT_POP)
         packed.mats = mats.as<rt_material>();
+        packed.perlin = dw.perlin; packed.image = dw.image; packed.image_w = dw.image_w; packed.image_h = dw.image_h;
         has_packed = true;
         return RT_OK;
     }
@@ -194,10 +195,14 @@ struct DeviceScene {
         for (uint32_t i = 0; i < w->n_quads; i++) {
             if (w->quads[i].mat >= w->n_materials) return rt_fail(RT_ERR_INVALID, "quad %u: material index out of range", i);
             if (w->materials[w->quads[i].mat].type == RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "quad %u: a constant medium is bounded by a sphere (RT_MAT_ISOTROPIC on a quad)", i);
+            if (w->materials[w->quads[i].mat].type == RT_MAT_LAMBERTIAN_IMAGE) return rt_fail(RT_ERR_INVALID, "quad %u: the image texture maps onto spheres only", i);
         }
         extended = w->n_quads != 0 || w->background != 0;
         for (uint32_t i = 0; i < w->n_materials; i++) {
-            if (w->materials[i].type > RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
+            if (w->materials[i].type > RT_MAT_LAMBERTIAN_IMAGE) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
+            if (w->materials[i].type == RT_MAT_LAMBERTIAN_NOISE && !w->perlin) return rt_fail(RT_ERR_INVALID, "material %u is a noise texture but the world has no Perlin tables (rt_scene_set_perlin)", i);
+            if (w->materials[i].type == RT_MAT_LAMBERTIAN_IMAGE && (!w->image || w->image_width == 0 || w->image_height == 0))
+                return rt_fail(RT_ERR_INVALID, "material %u is an image texture but the world has no image (rt_scene_set_image)", i);
             if (w->materials[i].type == RT_MAT_ISOTROPIC && !(w->materials[i].param > 0.0f)) return rt_fail(RT_ERR_INVALID, "material %u: a constant medium needs a density > 0", i);
             if (w->materials[i].type >= RT_MAT_DIFFUSE_LIGHT) extended = true;
         }
@@ -253,6 +258,11 @@ struct DeviceScene {
         dw.quads = quads.as<rt_quad>(); dw.n_quads = w->n_quads;
         dw.background = w->background;
         dw.background_color = mk3(w->background_color[0], w->background_color[1], w->background_color[2]);
+        HIP_TRY(perlin.upload(w->perlin, w->perlin ? sizeof(rt_perlin) : 0));
+        HIP_TRY(image.upload(w->image, w->image ? (size_t)w->image_width * w->image_height * 3 : 0));
+        dw.perlin = w->perlin ? perlin.as<rt_perlin>() : nullptr;
+        dw.image = w->image ? image.as<uint8_t>() : nullptr;
+        dw.image_w = w->image_width; dw.image_h = w->image_height;
         // 16-bit references and an LDS-resident image when that fits (2 x 768-thread workgroups per CU want <= 80 KiB each,
         // one workgroup may take all 160 KiB); otherwise 32-bit references and the records stay in global memory / L2
         int rc = pack(w, false);

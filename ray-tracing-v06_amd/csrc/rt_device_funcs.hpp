@@ -23,6 +23,9 @@ struct DeviceWorld {
     uint32_t n_quads;
     uint32_t background;
     f3 background_color;
+    const rt_perlin* perlin;   // RT_MAT_LAMBERTIAN_NOISE tables (global memory), or null
+    const uint8_t* image;      // RT_MAT_LAMBERTIAN_IMAGE RGB8 image, or null
+    uint32_t image_w, image_h;
 };
 
 // RayPayload (ray_data.cuh:33-40) with Sphere::TraceRecord (SphereHittable.cuh:38-41) unpacked
@@ -239,18 +242,72 @@ RT_HD f3 checker_value(f3 even, f3 odd, float inv_scale, f3 pos) {
     return mk3(is_even ? even.x : odd.x, is_even ? even.y : odd.y, is_even ? even.z : odd.z);
 }
 
+// perlin::noise / perlin_interp / turb and noise_texture::value of "The Next Week" (extension, not in the reference), fp32
+// in one fixed evaluation order; the sine is rt_sinf.
+RT_HD float perlin_noise(const rt_perlin* t, f3 p) {
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = (u * u) * (3.0f - 2.0f * u), vv = (v * v) * (3.0f - 2.0f * v), ww = (w * w) * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = t->perm[0][(i + di) & 255] ^ t->perm[1][(j + dj) & 255] ^ t->perm[2][(k + dk) & 255];
+                const float* c = t->randvec[idx];
+                float wx = u - (float)di, wy = v - (float)dj, wz = w - (float)dk;
+                float d = c[0] * wx + c[1] * wy + c[2] * wz;
+                float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+                accum += ((wi * wj) * wk) * d;
+            }
+    return accum;
+}
+RT_HD float perlin_turb(const rt_perlin* t, f3 p, int depth) {
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < depth; i++) {
+        accum += weight * perlin_noise(t, p);
+        weight *= 0.5f;
+        p = p * 2.0f;
+    }
+    return fabsf(accum);
+}
+RT_HD f3 noise_value(const rt_perlin* t, f3 albedo, float scale, f3 p) {
+    return albedo * (1.0f + rt_sinf(scale * p.z + 10.0f * perlin_turb(t, p, 7)));
+}
+// sphere::get_sphere_uv + image_texture::value of "The Next Week" (extension): n = outward unit normal of the sphere
+RT_HD f3 image_value(const uint8_t* image, uint32_t width, uint32_t height, f3 n) {
+    float cy = -n.y;
+    cy = cy < -1.0f ? -1.0f : (cy > 1.0f ? 1.0f : cy);   // the normal is unit only up to rounding
+    float theta = rt_acosf(cy);
+    float phi = rt_atan2f(-n.z, n.x) + 0x1.921fb6p+1f;
+    float u = phi / 0x1.921fb6p+2f, v = theta / 0x1.921fb6p+1f;
+    u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    v = 1.0f - v;   // flip to image coordinates
+    int i = (int)(u * (float)width), j = (int)(v * (float)height);
+    if (i > (int)width - 1) i = (int)width - 1;
+    if (j > (int)height - 1) j = (int)height - 1;
+    const uint8_t* px = image + ((size_t)j * width + (size_t)i) * 3u;
+    return mk3((float)px[0] * 0x1.010102p-8f, (float)px[1] * 0x1.010102p-8f, (float)px[2] * 0x1.010102p-8f);
+}
+
 // Material::Scatter — LambertianAbstract (cu_materials.cuh:52-64), MetalAbstract (:77-95),
 // DielectricAbstract (:115-143), LambertianTexture (:27-40)
-RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRec& rec, Rng& rng, Ray& out, f3& attenuation) {
+// `w`: the world's Perlin tables / image for the two textured extension materials (may be null otherwise)
+RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRec& rec, Rng& rng, Ray& out, f3& attenuation,
+                            const DeviceWorld* w = nullptr) {
     f3 normal = rec.normal;
     if (m.type == RT_MAT_DIFFUSE_LIGHT) return false;  // diffuse_light of "The Next Week": emits, never scatters
     const f3 albedo = mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
     const f3 albedo2 = mk3(m.albedo2[0], m.albedo2[1], m.albedo2[2]);
-    if (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LAMBERTIAN_CHECKER) {
+    if (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LAMBERTIAN_CHECKER || m.type == RT_MAT_LAMBERTIAN_NOISE || m.type == RT_MAT_LAMBERTIAN_IMAGE) {
         f3 ray_dir = normal + rng_on_unit3(rng);
         if (near_zero(ray_dir)) return false;
         out.o = ray_at(in_ray, rec.distance); out.d = ray_dir; out.time = in_ray.time;
-        attenuation = (m.type == RT_MAT_LAMBERTIAN) ? albedo : checker_value(albedo, albedo2, m.param, ray_at(in_ray, rec.distance));
+        if (m.type == RT_MAT_LAMBERTIAN) attenuation = albedo;
+        else if (m.type == RT_MAT_LAMBERTIAN_CHECKER) attenuation = checker_value(albedo, albedo2, m.param, ray_at(in_ray, rec.distance));
+        else if (m.type == RT_MAT_LAMBERTIAN_NOISE) attenuation = noise_value(w->perlin, albedo, m.param, ray_at(in_ray, rec.distance));
+        else attenuation = image_value(w->image, w->image_w, w->image_h, normal);
         return true;
     }
     if (m.type == RT_MAT_ISOTROPIC) {  // isotropic phase function of "The Next Week": a uniformly random direction, always scatters
@@ -328,7 +385,7 @@ __device__ inline f3 sample_world(const DeviceWorld& w, Ray cur_ray, uint32_t ma
         if (m.type == RT_MAT_DIFFUSE_LIGHT) accum_radiance = accum_radiance + accum_attenuation * mk3(m.albedo[0], m.albedo[1], m.albedo[2]);
         Ray scattered;
         f3 attenuation;
-        if (!material_scatter(m, cur_ray, rec, rng, scattered, attenuation)) return accum_radiance;
+        if (!material_scatter(m, cur_ray, rec, rng, scattered, attenuation, &w)) return accum_radiance;
         accum_attenuation = accum_attenuation * attenuation;
         cur_ray = scattered;
         cur_ray.o = cur_ray.o + cur_ray.d * 0.001f;

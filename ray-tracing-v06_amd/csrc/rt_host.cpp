@@ -118,6 +118,9 @@ struct rt_scene {
     uint32_t background = 0;
     float background_color[3] = {0.0f, 0.0f, 0.0f};
     std::vector<rt_material> mats;
+    std::vector<rt_perlin> perlin;        // 0 or 1 table set (RT_MAT_LAMBERTIAN_NOISE)
+    std::vector<uint8_t> image;           // RGB8 (RT_MAT_LAMBERTIAN_IMAGE)
+    uint32_t image_w = 0, image_h = 0;
     std::vector<rt_bvh_node> nodes;       // world nodes (BVH or bvh_node tree)
     std::vector<rt_bvh_node> tree_nodes;  // bvh_node objects created by rt_scene_add_bvh_node
     uint32_t kind = RT_WORLD_LIST;
@@ -137,7 +140,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) { delete s; }
 extern "C" int rt_scene_add_material(rt_scene* s, uint32_t type, const float albedo[3], float param,
                                      const float albedo2[3], int32_t* out_id) {
     if (!s || !albedo) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: null argument");
-    if (type > RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: unknown material type %u", type);
+    if (type > RT_MAT_LAMBERTIAN_IMAGE) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: unknown material type %u", type);
     if (type == RT_MAT_ISOTROPIC && !(param > 0.0f)) return rt_fail(RT_ERR_INVALID, "rt_scene_add_material: a constant medium needs a density > 0");
     rt_material m;
     std::memset(&m, 0, sizeof(m));
@@ -442,6 +445,46 @@ extern "C" int rt_scene_get_flat(const rt_scene* s, rt_world_flat* out) {
     out->n_quads = (uint32_t)s->quads.size();
     out->background = s->background;
     st3(out->background_color, ld3(s->background_color));
+    out->perlin = s->perlin.empty() ? nullptr : s->perlin.data();
+    out->image = s->image.empty() ? nullptr : s->image.data();
+    out->image_width = s->image_w;
+    out->image_height = s->image_h;
+    return RT_OK;
+}
+
+// perlin::perlin() ("The Next Week"): randvec[i] = unit_vector(vec3::random(-1, 1)); perm = identity shuffled by
+// `for i = n-1 .. 1: swap(p[i], p[random_int(0, i)])`, three times.  Uniforms: the build's sequential host stream, id 0x9E81.
+extern "C" int rt_scene_set_perlin(rt_scene* s, uint64_t seed) {
+    if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_perlin: null scene");
+    Rng g;
+    g.init(seed, 0u, 0u, 0x9E81u);
+    s->perlin.assign(1, rt_perlin());
+    rt_perlin& t = s->perlin[0];
+    for (int i = 0; i < 256; i++) {
+        f3 v;
+        v.x = g.next() * 2.0f - 1.0f;
+        v.y = g.next() * 2.0f - 1.0f;
+        v.z = g.next() * 2.0f - 1.0f;
+        if (near_zero(v)) v = mk3(1.0f, 0.0f, 0.0f);
+        st3(t.randvec[i], normalize(v));
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < 256; i++) t.perm[k][i] = i;
+        for (int i = 255; i > 0; i--) {
+            int target = (int)(g.next() * (float)(i + 1));   // random_int(0, i); the uniform is in (0, 1]
+            if (target > i) target = i;
+            int32_t tmp = t.perm[k][i]; t.perm[k][i] = t.perm[k][target]; t.perm[k][target] = tmp;
+        }
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_image(rt_scene* s, uint32_t width, uint32_t height, const uint8_t* rgb) {
+    if (!s || !rgb) return rt_fail(RT_ERR_INVALID, "rt_scene_set_image: null argument");
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 26)) return rt_fail(RT_ERR_INVALID, "rt_scene_set_image: bad size %u x %u", width, height);
+    s->image.assign(rgb, rgb + (size_t)width * height * 3);
+    s->image_w = width;
+    s->image_h = height;
     return RT_OK;
 }
 

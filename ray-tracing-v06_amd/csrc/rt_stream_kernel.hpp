@@ -86,6 +86,9 @@ struct PackedSceneRef {
     uint32_t stack_cap;      // entries per lane
     uint32_t n_inner, n_codes, n_prims;
     const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
+    const rt_perlin* perlin; // EXT: noise tables / image of the two textured materials (global memory), or null
+    const uint8_t* image;
+    uint32_t image_w, image_h;
 };
 
 struct StreamParams {
@@ -544,6 +547,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                             const rt_material& mg = p.scene.mats[mat_bits & RT_MAT_INDEX_MASK];
                             albedo = checker_value(albedo, mk3(mg.albedo2[0], mg.albedo2[1], mg.albedo2[2]), mparam, hit_p);
                         }
+                        if (EXT && mtype == RT_MAT_LAMBERTIAN_NOISE) albedo = noise_value(p.scene.perlin, albedo, mparam, hit_p);
+                        if (EXT && mtype == RT_MAT_LAMBERTIAN_IMAGE) albedo = image_value(p.scene.image, p.scene.image_w, p.scene.image_h, normal);
                     }
                 }
                 RT_PT(13);

@@ -34,7 +34,8 @@ class World(C.Structure):
                 ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3),
                 ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p),
                 ("quads", C.c_void_p), ("n_quads", C.c_uint32), ("background", C.c_uint32),
-                ("background_color", C.c_float * 3), ("reserved", C.c_uint32)]
+                ("background_color", C.c_float * 3), ("image_width", C.c_uint32),
+                ("perlin", C.c_void_p), ("image", C.c_void_p), ("image_height", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -85,6 +86,8 @@ def lib():
     L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
     L.orc_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
     L.orc_math_batch.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
+    L.orc_scene_set_perlin.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_scene_set_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.orc_aabb_batch.argtypes = [C.c_size_t, f32p, f32p, f32p, i32p, f32p]
     L.orc_sphere_batch.argtypes = [C.c_size_t, f32p, f32p, f32p]
     L.orc_trace_batch.argtypes = [C.POINTER(World), C.c_size_t, f32p, i32p, f32p, i32p, f32p]
@@ -179,6 +182,22 @@ class Scene:
     @property
     def quads(self):
         return self._arr(self.world.quads, self.world.n_quads, QUAD_DT)
+
+    def set_perlin(self, seed=1984):
+        lib().orc_scene_set_perlin(self.h, seed)
+        lib().orc_scene_world(self.h, C.byref(self.world))
+        return self
+
+    def set_image(self, rgb):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        lib().orc_scene_set_image(self.h, rgb.shape[1], rgb.shape[0], rgb.ctypes.data)
+        lib().orc_scene_world(self.h, C.byref(self.world))
+        return self
+
+    @property
+    def perlin(self):
+        buf = (C.c_char * 6144).from_address(self.world.perlin)
+        return bytes(buf)
 
     @property
     def materials(self):

@@ -252,3 +252,63 @@ def test_camera_inside_a_global_fog(p):
         else:
             assert bits_equal(img, ref), f"variant {variant}: " + mismatch_report(img, ref)
     assert ref[..., :3].max() > 0.5 and ref[..., :3].mean() > 0.01
+
+
+# ------------------------------------------------------------------------------------------------
+# Perlin noise (marble) and image textures
+# ------------------------------------------------------------------------------------------------
+def _test_image(h=48, w=96):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 3), np.uint8)
+    img[..., 0] = (xx * 255 // (w - 1)).astype(np.uint8)
+    img[..., 1] = (yy * 255 // (h - 1)).astype(np.uint8)
+    img[..., 2] = (((xx // 8) + (yy // 8)) % 2 * 200 + 30).astype(np.uint8)
+    return img
+
+
+def test_noise_and_image_textures_render_bit_exact(p):
+    """lambertian(noise_texture) on a sphere, the ground and a quad, lambertian(image_texture) on spheres (one of them
+    moving): every variant against the oracle."""
+    s = p.Scene()
+    s.set_perlin(1984).set_image(_test_image())
+    marble = s.NoiseTexture(4.0)
+    marble2 = s.NoiseTexture(0.7, (0.4, 0.5, 0.3))
+    earth = s.ImageTexture()
+    s.MakeSphere((0, -1000, 0), 1000.0, marble2)
+    s.MakeSphere((0, 2, 0), 2.0, marble)
+    s.MakeSphere((4, 1.2, 1.5), 1.2, earth)
+    s.MakeMovingSphere((-3.5, 1, 2.5), (-3.5, 1.6, 2.5), 1.0, earth)
+    s.MakeQuad((-6, 0.5, -4), (5, 0, 0), (0, 4, 0), marble)
+    s.MakeQuad((3, 5, -2), (2, 0, 0), (0, 0, 2), s.DiffuseLight((6, 6, 6)))
+    s.set_background((0.35, 0.4, 0.5))
+    s.BuildBVH_TopDown()
+    W, H, spp = 150, 100, 12
+    cam = p.MotionBlurCamera((10, 4, 9), (0, 1.5, 0), (0, 1, 0), 35.0, W / H, 0.0, 1.0)
+    for variant in (0, 1, 2):
+        img, ref = _render_both(p, s, cam, W, H, spp, variant=variant)
+        if variant == 1:
+            assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED
+        else:
+            assert bits_equal(img, ref), f"variant {variant}: " + mismatch_report(img, ref)
+    # the textures are visible: the image sphere shows a wide range of colours
+    assert ref[..., 0].std() > 0.05 and ref[..., 1].std() > 0.05
+
+
+def test_textured_materials_need_their_tables(p):
+    s = p.Scene()
+    s.MakeSphere((0, 0, 0), 1.0, s.NoiseTexture(2.0))
+    s.BuildBVH_TopDown()
+    cam = p.PinholeCamera((0, 0, 5), (0, 0, 0), (0, 1, 0), 40.0, 1.0)
+    with pytest.raises(p.capi.RtError, match="Perlin"):
+        p.Renderer.MakeRenderer(16, 16, 1, 5, cam, s.getWorldPtr())
+    s2 = p.Scene()
+    s2.MakeSphere((0, 0, 0), 1.0, s2.ImageTexture())
+    s2.BuildBVH_TopDown()
+    with pytest.raises(p.capi.RtError, match="image"):
+        p.Renderer.MakeRenderer(16, 16, 1, 5, cam, s2.getWorldPtr())
+    s3 = p.Scene()
+    s3.set_image(_test_image())
+    s3.MakeQuad((0, 0, 0), (1, 0, 0), (0, 1, 0), s3.ImageTexture())
+    s3.BuildBVH_TopDown()
+    with pytest.raises(p.capi.RtError, match="spheres only"):
+        p.Renderer.MakeRenderer(16, 16, 1, 5, cam, s3.getWorldPtr())

@@ -30,7 +30,7 @@ def test_struct_layouts_match_header_sizes():
     p = pkg()
     assert p.capi.NODE_DT.itemsize == 32 and p.capi.PRIM_DT.itemsize == 32 and p.capi.MAT_DT.itemsize == 32
     assert C.sizeof(p.capi.Camera) == 76
-    assert C.sizeof(p.capi.WorldFlat) == C.sizeof(O.World) == 104
+    assert C.sizeof(p.capi.WorldFlat) == C.sizeof(O.World) == 128
     assert C.sizeof(p.capi.Camera) == C.sizeof(O.Camera)
 
 
@@ -212,3 +212,22 @@ def test_oracle_renders_config1_three_spheres():
     # thread-count independence of the oracle itself
     img1, _ = O.render(o.world, cam, 400, 225, 1, 50, threads=1)
     assert img1.tobytes() == img.tobytes()
+
+
+def test_perlin_tables_match_oracle_bit_for_bit():
+    """perlin::perlin() (extension): 256 unit vectors + three permutations from the host stream — product host code vs oracle."""
+    p = pkg()
+    s = p.Scene()
+    m = s.set_perlin(77).NoiseTexture(4.0)
+    s.MakeSphere((0, 0, 0), 1.0, m)
+    s.BuildBVH_TopDown()
+    w = s.getWorldPtr()
+    got = bytes((C.c_char * 6144).from_address(w.perlin))
+    o = O.Scene.three_spheres().set_perlin(77)
+    assert got == o.perlin
+    t = np.frombuffer(got, dtype=np.float32, count=768).reshape(256, 3)
+    assert np.allclose(np.linalg.norm(t, axis=1), 1.0, atol=1e-6)
+    perm = np.frombuffer(got, dtype=np.int32, offset=3072).reshape(3, 256)
+    for k in range(3):
+        assert sorted(perm[k].tolist()) == list(range(256)) and perm[k].tolist() != list(range(256))
+    assert not np.array_equal(perm[0], perm[1])
