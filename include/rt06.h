@@ -235,6 +235,13 @@ int rt_scene_three_spheres(rt_scene** out);
 /* BASELINE.json configs[3]: the Cornell box of "The Next Week" (5 walls, light, two rotated boxes = 18 quads),
  * black background, median-split BVH.  Not in the reference (no quads / emission there).                  */
 int rt_scene_cornell_box(rt_scene** out);
+/* box(a, b, mat) of "The Next Week" as 6 quads, rotated about y and translated on the host (the book wraps instances) */
+int rt_scene_add_box(rt_scene* s, const float a[3], const float b[3], int32_t mat, float rotate_y_degrees,
+                     const float translate[3], int32_t* out_first_quad);
+/* BASELINE.json configs[4]: final_scene() of "The Next Week" — 2401 quads, 1008 spheres, two constant media, a marble
+ * and an image texture (a synthetic planet stands in for earthmap.jpg), black background, median-split BVH.  Not in the
+ * reference.  Camera of the book: lookfrom (478,278,-600), lookat (278,278,0), vfov 40, time 0..1.               */
+int rt_scene_book2_final(uint64_t seed, rt_scene** out);
 
 /* ------------------------------------------------------------------ */
 /* Renderer — main/src/Renderer.h:38-46                                */

@@ -1199,6 +1199,79 @@ orc_scene* orc_scene_cornell_box(void) {
     float black[3] = {0, 0, 0};
     return orc_scene_from_arrays_ext(0, NULL, n, quads, 4, mats, 0, 1, black);
 }
+/* final_scene() of "Ray Tracing: The Next Week" (BASELINE.json configs[4], nothing of it in the reference); the synthetic
+ * planet replaces earthmap.jpg (integer arithmetic only).  Draw order: one uniform per ground box, then three per small
+ * sphere, from the host stream. */
+void orc_scene_set_perlin(orc_scene* s, uint64_t seed);
+void orc_scene_set_image(orc_scene* s, uint32_t width, uint32_t height, const uint8_t* rgb);
+static void synthetic_earth(uint8_t* img, uint32_t w, uint32_t h) {
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            uint32_t f = (x * x / 64u + y * y / 32u + x * y / 128u + 3u * x) % 64u;
+            int land = f < 26u, ice = y < 9u || y > 118u;
+            uint8_t* px = &img[((size_t)y * w + x) * 3];
+            if (ice) { px[0] = 235; px[1] = 240; px[2] = 245; }
+            else if (land) { px[0] = (uint8_t)(60u + 2u * f); px[1] = (uint8_t)(120u + f); px[2] = 50; }
+            else { px[0] = 25; px[1] = (uint8_t)(60u + f / 2u); px[2] = (uint8_t)(140u + f); }
+        }
+}
+static void b2_sphere(orc_prim* prims, size_t* n, v3 c0, v3 c1, float r, uint32_t mat, int moving) {
+    orc_prim* p = &prims[(*n)++];
+    st3(p->c0, c0); st3(p->c1, c1); p->radius = r; p->mat = mat | (moving ? ORC_PRIM_MOVING : 0u);
+}
+static void b2_mat(orc_material* m, uint32_t type, v3 albedo, float param) {
+    memset(m, 0, sizeof(*m));
+    st3(m->albedo, albedo); m->param = param; m->type = type;
+}
+orc_scene* orc_scene_book2_final(uint64_t seed) {
+    orc_prim* prims = (orc_prim*)calloc(1008, sizeof(orc_prim));
+    orc_quad* quads = (orc_quad*)calloc(2401, sizeof(orc_quad));
+    orc_material mats[10];
+    size_t np = 0, nq = 0;
+    rng_t g; rng_init(&g, seed, 0u, 0u, 0x5CE9E5u);
+    b2_mat(&mats[0], 0, V(0.48f, 0.83f, 0.53f), 0.0f);          /* ground */
+    for (int i = 0; i < 20; i++)
+        for (int j = 0; j < 20; j++) {
+            const float w = 100.0f;
+            float x0 = -1000.0f + (float)i * w, z0 = -1000.0f + (float)j * w, y0 = 0.0f;
+            float x1 = x0 + w, y1 = 1.0f + 100.0f * rng_next(&g), z1 = z0 + w;
+            cornell_box(quads, &nq, V(x0, y0, z0), V(x1, y1, z1), 0.0f, V(0, 0, 0), 0);
+        }
+    b2_mat(&mats[1], 4, V(7.0f, 7.0f, 7.0f), 0.0f);              /* light */
+    cornell_quad(quads, &nq, V(123, 554, 147), V(300, 0, 0), V(0, 0, 265), 1);
+    b2_mat(&mats[2], 0, V(0.7f, 0.3f, 0.1f), 0.0f);
+    b2_sphere(prims, &np, V(400, 400, 200), V(430, 400, 200), 50.0f, 2, 1);
+    b2_mat(&mats[3], 2, V(1.0f, 1.0f, 1.0f), 1.5f);              /* glass */
+    b2_sphere(prims, &np, V(260, 150, 45), V(260, 150, 45), 50.0f, 3, 0);
+    b2_mat(&mats[4], 1, V(0.8f, 0.8f, 0.9f), 1.0f);
+    b2_sphere(prims, &np, V(0, 150, 145), V(0, 150, 145), 50.0f, 4, 0);
+    b2_sphere(prims, &np, V(360, 150, 145), V(360, 150, 145), 70.0f, 3, 0);
+    b2_mat(&mats[5], 5, V(0.2f, 0.4f, 0.9f), 0.2f);              /* blue medium inside the glass ball */
+    b2_sphere(prims, &np, V(360, 150, 145), V(360, 150, 145), 70.0f, 5, 0);
+    b2_mat(&mats[6], 5, V(1.0f, 1.0f, 1.0f), 0.0001f);           /* global fog */
+    b2_sphere(prims, &np, V(0, 0, 0), V(0, 0, 0), 5000.0f, 6, 0);
+    b2_mat(&mats[7], 7, V(1.0f, 1.0f, 1.0f), 0.0f);              /* image texture */
+    b2_sphere(prims, &np, V(400, 200, 400), V(400, 200, 400), 100.0f, 7, 0);
+    b2_mat(&mats[8], 6, V(0.5f, 0.5f, 0.5f), 0.2f);              /* marble */
+    b2_sphere(prims, &np, V(220, 280, 300), V(220, 280, 300), 80.0f, 8, 0);
+    b2_mat(&mats[9], 0, V(0.73f, 0.73f, 0.73f), 0.0f);
+    float rad = radians(15.0f), c = cosf(rad), sn = sinf(rad);
+    for (int j = 0; j < 1000; j++) {
+        v3 ctr;
+        ctr.x = 165.0f * rng_next(&g); ctr.y = 165.0f * rng_next(&g); ctr.z = 165.0f * rng_next(&g);
+        v3 pos = add(rot_y(ctr, c, sn), V(-100, 270, 395));
+        b2_sphere(prims, &np, pos, pos, 10.0f, 9, 0);
+    }
+    float black[3] = {0, 0, 0};
+    orc_scene* s = orc_scene_from_arrays_ext(np, prims, nq, quads, 10, mats, 0, 1, black);
+    free(prims); free(quads);
+    uint8_t* img = (uint8_t*)malloc(256 * 128 * 3);
+    synthetic_earth(img, 256, 128);
+    orc_scene_set_image(s, 256, 128, img);
+    free(img);
+    orc_scene_set_perlin(s, seed);
+    return s;
+}
 void orc_scene_world(const orc_scene* s, orc_world* out) { *out = s->world; }
 /* perlin::perlin() of "The Next Week": randvec[i] = unit_vector(random(-1,1)^3); perm = identity shuffled by
  * `for i = n-1 .. 1: swap(p[i], p[random_int(0, i)])`, three times; uniforms from the host stream, id 0x9E81 */

@@ -159,6 +159,7 @@ orc_scene* orc_scene_from_arrays_ext(size_t n_prims, const orc_prim* prims, size
                                      const float background_color[3]);
 /* the Cornell box of "The Next Week" (BASELINE.json configs[3]): 5 walls, a light, two rotated boxes as 12 quads */
 orc_scene* orc_scene_cornell_box(void);
+orc_scene* orc_scene_book2_final(uint64_t seed);
 void orc_scene_world(const orc_scene* s, orc_world* out);
 /* perlin::perlin() from the build's host stream (id 0x9E81) / the image of image_texture, attached to a scene */
 void orc_scene_set_perlin(orc_scene* s, uint64_t seed);

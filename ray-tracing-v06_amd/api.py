@@ -70,6 +70,13 @@ class Scene:
         check(lib().rt_scene_cornell_box(C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def book2_final(cls, seed=1984):
+        """BASELINE.json configs[4] (not in the reference): final_scene() of "The Next Week"."""
+        h = C.c_void_p()
+        check(lib().rt_scene_book2_final(seed, C.byref(h)))
+        return cls(h)
+
     # --- vocabulary ---
     def add_material(self, mtype, albedo, param=0.0, albedo2=None):
         out = C.c_int32()
@@ -120,6 +127,12 @@ class Scene:
     def ImageTexture(self):
         """lambertian(image_texture) of "The Next Week" on spheres (extension); needs set_image()."""
         return self.add_material(capi.MAT_LAMBERTIAN_IMAGE, (1, 1, 1))
+
+    def MakeBox(self, a, b, mat, rotate_y=0.0, translate=(0, 0, 0)):
+        """box(a, b, mat) of "The Next Week" as 6 quads, optionally rotate_y(degrees) then translate; returns the first quad index."""
+        out = C.c_int32()
+        check(lib().rt_scene_add_box(self.h, v3(a), v3(b), mat, rotate_y, v3(translate), C.byref(out)))
+        return out.value
 
     def MakeQuad(self, Q, u, v, mat):
         """quad(Q,u,v,mat) of "The Next Week" (extension, not in the reference)."""
@@ -203,6 +216,17 @@ class Scene:
     def quads(self):
         w = self.getWorldPtr()
         return self._arr(w.quads, w.n_quads, capi.QUAD_DT)
+
+    def perlin_bytes(self):
+        w = self.getWorldPtr()
+        return bytes((C.c_char * 6144).from_address(w.perlin)) if w.perlin else b""
+
+    def image(self):
+        w = self.getWorldPtr()
+        if not w.image:
+            return np.zeros((0, 0, 3), np.uint8)
+        buf = (C.c_char * (w.image_width * w.image_height * 3)).from_address(w.image)
+        return np.frombuffer(buf, dtype=np.uint8).reshape(w.image_height, w.image_width, 3).copy()
 
     def __del__(self):
         try:

@@ -63,7 +63,7 @@ class RtError(RuntimeError):
 SYMBOLS = [
     "rt_last_error", "rt_camera_pinhole", "rt_camera_defocus", "rt_camera_motion",
     "rt_scene_create", "rt_scene_destroy", "rt_scene_add_material", "rt_scene_add_sphere",
-    "rt_scene_add_moving_sphere", "rt_scene_add_quad", "rt_scene_set_background", "rt_scene_set_perlin", "rt_scene_set_image", "rt_scene_cornell_box", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
+    "rt_scene_add_moving_sphere", "rt_scene_add_quad", "rt_scene_set_background", "rt_scene_set_perlin", "rt_scene_set_image", "rt_scene_cornell_box", "rt_scene_add_box", "rt_scene_book2_final", "rt_scene_prim_bounds", "rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah",
     "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list", "rt_scene_add_bvh_node",
     "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
     "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
@@ -131,6 +131,8 @@ def lib():
     L.rt_scene_set_perlin.argtypes = [C.c_void_p, C.c_uint64]
     L.rt_scene_set_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.rt_scene_cornell_box.argtypes = [P(C.c_void_p)]
+    L.rt_scene_add_box.argtypes = [C.c_void_p, vec3, vec3, C.c_int32, C.c_float, vec3, P(C.c_int32)]
+    L.rt_scene_book2_final.argtypes = [C.c_uint64, P(C.c_void_p)]
     L.rt_scene_prim_bounds.argtypes = [C.c_void_p, C.c_int32, vec3, vec3]
     for n in ("rt_scene_build_bvh_topdown", "rt_scene_build_bvh_sah", "rt_scene_build_bvh_bottomup", "rt_scene_set_world_list"):
         getattr(L, n).argtypes = [C.c_void_p]

@@ -588,6 +588,89 @@ static void cornell_box(rt_scene* s, f3 a, f3 b, float degrees, f3 offset, int32
     f3 vs[6] = {dy, dy, dy, dy, -dz, dz};
     for (int k = 0; k < 6; k++) cornell_quad(s, rot_y(Qs[k], c, sn) + offset, rot_y(us[k], c, sn), rot_y(vs[k], c, sn), mat);
 }
+extern "C" int rt_scene_add_box(rt_scene* s, const float a[3], const float b[3], int32_t mat, float rotate_y_degrees,
+                                const float translate[3], int32_t* out_first_quad) {
+    if (!s || !a || !b) return rt_fail(RT_ERR_INVALID, "rt_scene_add_box: null argument");
+    if (mat < 0 || (size_t)mat >= s->mats.size()) return rt_fail(RT_ERR_INVALID, "rt_scene_add_box: material %d out of range", mat);
+    if (out_first_quad) *out_first_quad = (int32_t)s->quads.size();
+    cornell_box(s, ld3(a), ld3(b), rotate_y_degrees, translate ? ld3(translate) : mk3(0.0f), mat);
+    return RT_OK;
+}
+
+// The image the book loads from earthmap.jpg is not redistributable here: a synthetic 256 x 128 "planet" (integer
+// arithmetic only, so that the oracle generates the same bytes): oceans, land masses, polar caps.
+static void synthetic_earth(std::vector<uint8_t>& img, uint32_t& w, uint32_t& h) {
+    w = 256; h = 128;
+    img.resize((size_t)w * h * 3);
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            uint32_t f = (x * x / 64u + y * y / 32u + x * y / 128u + 3u * x) % 64u;
+            bool land = f < 26u, ice = y < 9u || y > 118u;
+            uint8_t* px = &img[((size_t)y * w + x) * 3];
+            if (ice) { px[0] = 235; px[1] = 240; px[2] = 245; }
+            else if (land) { px[0] = (uint8_t)(60u + 2u * f); px[1] = (uint8_t)(120u + f); px[2] = 50; }
+            else { px[0] = 25; px[1] = (uint8_t)(60u + f / 2u); px[2] = (uint8_t)(140u + f); }
+        }
+}
+
+// final_scene() of "Ray Tracing: The Next Week" (BASELINE.json configs[4]; nothing of it exists in the reference):
+// 400 ground boxes of random height (2400 quads), an area light, a moving sphere, glass, metal, a glass ball filled with a
+// blue medium, a thin global fog, an image-textured sphere, a marble sphere and a rotated, translated cluster of 1000 small
+// spheres, under ONE median-split BVH.  Uniforms: the host stream of rt_host_uniforms(seed), one per box, three per sphere.
+extern "C" int rt_scene_book2_final(uint64_t seed, rt_scene** out) {
+    if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_book2_final: null out");
+    rt_scene* s = new rt_scene();
+    Rng g;
+    g.init(seed, 0u, 0u, RT_STREAM_SCENE);
+    auto material = [&](uint32_t type, f3 albedo, float param) {
+        float a[3]; st3(a, albedo);
+        int32_t id = 0;
+        rt_scene_add_material(s, type, a, param, nullptr, &id);
+        return id;
+    };
+    auto sphere = [&](f3 c, float r, int32_t mat) { float p[3]; st3(p, c); add_prim(s, p, p, r, mat, false, nullptr); };
+    const int32_t ground = material(RT_MAT_LAMBERTIAN, mk3(0.48f, 0.83f, 0.53f), 0.0f);
+    for (int i = 0; i < 20; i++)
+        for (int j = 0; j < 20; j++) {
+            const float w = 100.0f;
+            float x0 = -1000.0f + (float)i * w, z0 = -1000.0f + (float)j * w, y0 = 0.0f;
+            float x1 = x0 + w, y1 = 1.0f + 100.0f * g.next(), z1 = z0 + w;
+            cornell_box(s, mk3(x0, y0, z0), mk3(x1, y1, z1), 0.0f, mk3(0.0f), ground);
+        }
+    cornell_quad(s, mk3(123, 554, 147), mk3(300, 0, 0), mk3(0, 0, 265), material(RT_MAT_DIFFUSE_LIGHT, mk3(7.0f), 0.0f));
+    {
+        float c0[3] = {400, 400, 200}, c1[3] = {430, 400, 200};
+        add_prim(s, c0, c1, 50.0f, material(RT_MAT_LAMBERTIAN, mk3(0.7f, 0.3f, 0.1f), 0.0f), true, nullptr);
+    }
+    const int32_t glass = material(RT_MAT_DIELECTRIC, mk3(1.0f), 1.5f);
+    sphere(mk3(260, 150, 45), 50.0f, glass);
+    sphere(mk3(0, 150, 145), 50.0f, material(RT_MAT_METAL, mk3(0.8f, 0.8f, 0.9f), 1.0f));
+    sphere(mk3(360, 150, 145), 70.0f, glass);
+    sphere(mk3(360, 150, 145), 70.0f, material(RT_MAT_ISOTROPIC, mk3(0.2f, 0.4f, 0.9f), 0.2f));
+    sphere(mk3(0, 0, 0), 5000.0f, material(RT_MAT_ISOTROPIC, mk3(1.0f), 0.0001f));
+    {
+        uint32_t w = 0, h = 0;
+        synthetic_earth(s->image, w, h);
+        s->image_w = w; s->image_h = h;
+    }
+    sphere(mk3(400, 200, 400), 100.0f, material(RT_MAT_LAMBERTIAN_IMAGE, mk3(1.0f), 0.0f));
+    rt_scene_set_perlin(s, seed);
+    sphere(mk3(220, 280, 300), 80.0f, material(RT_MAT_LAMBERTIAN_NOISE, mk3(0.5f), 0.2f));
+    const int32_t white = material(RT_MAT_LAMBERTIAN, mk3(0.73f), 0.0f);
+    const float rad = radians(15.0f), c = cosf(rad), sn = sinf(rad);
+    for (int j = 0; j < 1000; j++) {
+        f3 ctr;
+        ctr.x = 165.0f * g.next(); ctr.y = 165.0f * g.next(); ctr.z = 165.0f * g.next();
+        sphere(rot_y(ctr, c, sn) + mk3(-100, 270, 395), 10.0f, white);   // translate(rotate_y(.., 15), (-100, 270, 395))
+    }
+    const float black[3] = {0.0f, 0.0f, 0.0f};
+    rt_scene_set_background(s, 1, black);
+    int rc = rt_scene_build_bvh_topdown(s);
+    if (rc != RT_OK) { delete s; return rc; }
+    *out = s;
+    return RT_OK;
+}
+
 extern "C" int rt_scene_cornell_box(rt_scene** out) {
     if (!out) return rt_fail(RT_ERR_INVALID, "rt_scene_cornell_box: null out");
     rt_scene* s = new rt_scene();

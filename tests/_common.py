@@ -59,6 +59,8 @@ def config_cameras(p, which, W, H):
         return p.MotionBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.0, 1.0)
     if which == "cornell_box":    # config 4 (not in the reference): the book's Cornell camera
         return p.PinholeCamera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, W / H)
+    if which == "book2_final":    # config 5 (not in the reference): the book's final-scene camera, shutter 0..1
+        return p.MotionBlurCamera((478, 278, -600), (278, 278, 0), (0, 1, 0), 40.0, W / H, 0.0, 1.0)
     raise ValueError(which)
 
 

@@ -87,6 +87,8 @@ def lib():
     L.orc_rng_uniforms.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, f32p]
     L.orc_math_batch.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p]
     L.orc_scene_set_perlin.argtypes = [C.c_void_p, C.c_uint64]
+    L.orc_scene_book2_final.argtypes = [C.c_uint64]
+    L.orc_scene_book2_final.restype = C.c_void_p
     L.orc_scene_set_image.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.orc_aabb_batch.argtypes = [C.c_size_t, f32p, f32p, f32p, i32p, f32p]
     L.orc_sphere_batch.argtypes = [C.c_size_t, f32p, f32p, f32p]
@@ -144,6 +146,10 @@ class Scene:
     @classmethod
     def three_spheres(cls):
         return cls(lib().orc_scene_three_spheres())
+
+    @classmethod
+    def book2_final(cls, seed=1984):
+        return cls(lib().orc_scene_book2_final(seed))
 
     @classmethod
     def cornell_box(cls):

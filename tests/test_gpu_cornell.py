@@ -312,3 +312,19 @@ def test_textured_materials_need_their_tables(p):
     s3.BuildBVH_TopDown()
     with pytest.raises(p.capi.RtError, match="spheres only"):
         p.Renderer.MakeRenderer(16, 16, 1, 5, cam, s3.getWorldPtr())
+
+
+def test_book2_final_scene_renders_bit_exact(p):
+    """final_scene() of "The Next Week" (BASELINE configs[4]): too large for the LDS -> global-memory streaming kernel."""
+    W, H, spp, depth = 96, 96, 4, 40
+    s = config_scene(p, "book2_final")
+    cam = config_cameras(p, "book2_final", W, H)
+    w = s.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    assert r.kernel_info()["variant"] == 3 and not r.kernel_info()["lds_resident"]
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    r.close()
+    ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    assert ref[..., :3].max() == 1.0 and ref[..., :3].mean() > 0.02

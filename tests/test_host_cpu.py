@@ -231,3 +231,21 @@ def test_perlin_tables_match_oracle_bit_for_bit():
     for k in range(3):
         assert sorted(perm[k].tolist()) == list(range(256)) and perm[k].tolist() != list(range(256))
     assert not np.array_equal(perm[0], perm[1])
+
+
+def test_book2_final_prefab_matches_oracle_bit_for_bit():
+    """BASELINE configs[4] (extension): 2401 quads, 1008 spheres, 10 materials, Perlin tables, synthetic planet image."""
+    p = pkg()
+    s, o = p.Scene.book2_final(1984), O.Scene.book2_final(1984)
+    w, ow = s.getWorldPtr(), o.world
+    for f in ("kind", "root", "n_nodes", "n_prims", "n_materials", "max_stack", "n_quads", "background", "image_width", "image_height"):
+        assert getattr(w, f) == getattr(ow, f), f
+    assert (w.n_prims, w.n_quads, w.n_materials, w.n_nodes) == (1008, 2401, 10, 2 * 3409 - 1)
+    nodes, prims, mats = s.arrays()
+    assert nodes.tobytes() == o.nodes.tobytes() and prims.tobytes() == o.prims.tobytes() and mats.tobytes() == o.materials.tobytes()
+    assert s.quads().tobytes() == o.quads.tobytes()
+    assert s.perlin_bytes() == o.perlin
+    img = s.image()
+    oimg = bytes((C.c_char * (256 * 128 * 3)).from_address(ow.image))
+    assert img.shape == (128, 256, 3) and img.tobytes() == oimg
+    assert sorted(int(t) for t in mats["type"]) == [0, 0, 0, 1, 2, 4, 5, 5, 6, 7]

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as G
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--scene", default="book1_final", choices=["book1_final", "book2_moving", "three_spheres", "cornell_box"])
+ap.add_argument("--scene", default="book1_final", choices=["book1_final", "book2_moving", "three_spheres", "cornell_box", "book2_final"])
 ap.add_argument("--width", type=int, default=1200)
 ap.add_argument("--height", type=int, default=800)
 ap.add_argument("--spp", type=int, default=500)
@@ -27,6 +27,8 @@ if a.scene == "three_spheres":
     scene, cam = p.Scene.three_spheres(), p.PinholeCamera((0, 0, 0), (0, 0, -1), (0, 1, 0), 90.0, W / H)
 elif a.scene == "cornell_box":
     scene, cam = p.Scene.cornell_box(), p.PinholeCamera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, W / H)
+elif a.scene == "book2_final":
+    scene, cam = p.Scene.book2_final(a.seed), p.MotionBlurCamera((478, 278, -600), (278, 278, 0), (0, 1, 0), 40.0, W / H, 0.0, 1.0)
 elif a.scene == "book1_final":
     scene, cam = p.Scene.book1_final(a.seed), p.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
 else:
