@@ -66,6 +66,7 @@ static void write_wide_node(uint4* blob, bool big, uint32_t index, const float l
 struct DeviceScene {
     DevBuf nodes, prims, mats, blob, quads, perlin, image;
     bool extended = false;  // quads, an emissive material or a constant background: beyond the reference's feature set
+    bool textured = false;  // a Perlin or image material: the EXT = 2 kernels
     DeviceWorld dw{};
     PackedSceneRef packed{};  // valid when has_packed
     bool has_packed = false;
@@ -198,6 +199,7 @@ struct DeviceScene {
             if (w->materials[w->quads[i].mat].type == RT_MAT_LAMBERTIAN_IMAGE) return rt_fail(RT_ERR_INVALID, "quad %u: the image texture maps onto spheres only", i);
         }
         extended = w->n_quads != 0 || w->background != 0;
+        textured = false;
         for (uint32_t i = 0; i < w->n_materials; i++) {
             if (w->materials[i].type > RT_MAT_LAMBERTIAN_IMAGE) return rt_fail(RT_ERR_INVALID, "material %u: unknown type", i);
             if (w->materials[i].type == RT_MAT_LAMBERTIAN_NOISE && !w->perlin) return rt_fail(RT_ERR_INVALID, "material %u is a noise texture but the world has no Perlin tables (rt_scene_set_perlin)", i);
@@ -205,6 +207,7 @@ struct DeviceScene {
                 return rt_fail(RT_ERR_INVALID, "material %u is an image texture but the world has no image (rt_scene_set_image)", i);
             if (w->materials[i].type == RT_MAT_ISOTROPIC && !(w->materials[i].param > 0.0f)) return rt_fail(RT_ERR_INVALID, "material %u: a constant medium needs a density > 0", i);
             if (w->materials[i].type >= RT_MAT_DIFFUSE_LIGHT) extended = true;
+            if (w->materials[i].type >= RT_MAT_LAMBERTIAN_NOISE) textured = true;
         }
         if (w->kind == RT_WORLD_BVH) {
             if (w->root < 0 || (uint32_t)w->root >= w->n_nodes) return rt_fail(RT_ERR_INVALID, "BVH root out of range");
@@ -384,13 +387,18 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
+        const bool fast = variant == 3;
         if (scene.big) {
-            if (variant == 3) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, true, true>);
-            return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true, true>);
+            if (scene.textured) return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 2, true>)
+                                            : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 2, true>);
+            return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 1, true>)
+                        : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 1, true>);
         }
         if (scene.extended) {
-            if (variant == 3) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, true>);
-            return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, true>);
+            if (scene.textured) return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 2>)
+                                            : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 2>);
+            return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 1>)
+                        : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 1>);
         }
         if (scene.dw.kind == RT_WORLD_LIST) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST>);
         if (scene.dw.kind == RT_WORLD_NODE_TREE) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_NODE_TREE>);

@@ -144,11 +144,13 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 // WORLD: RT_WORLD_BVH (default), RT_WORLD_LIST (HittableList: bounds pre-test, then every sphere in order;
 //        a reference is RT_REF_LEAF | primitive index and the "traversal" is the leaf phase alone) or
 //        RT_WORLD_NODE_TREE (bvh_node: a node is tested against ITS OWN box when visited, then left, then right).
-// EXT = true: the scene uses features the reference does not have (quads, diffuse lights, a constant background):
+// EXT >= 1: the scene uses features the reference does not have (quads, diffuse lights, a constant background, constant
+//        media; EXT = 2 adds the two textured materials — Perlin marble and the image texture — whose code is large enough
+//        to cost the other kernels registers):
 //        leaf codes >= sphere_codes are quads, emitted radiance is accumulated along the path (the reference's
 //        commented `accum_radiance`), the miss colour may be a constant.  A separate instantiation, so the
 //        reference-feature kernels carry none of it.
-template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, bool EXT = false, bool BIG = false>
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -275,14 +277,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 uint32_t n_inner_lanes;
                 do {
                     if (at_inner) {
-                        const char* nb = nodes + cur * K_NODE_BYTES;
-                        const float* px = reinterpret_cast<const float*>(nb + kx);
-                        const float* py = reinterpret_cast<const float*>(nb + ky);
-                        const float* pz = reinterpret_cast<const float*>(nb + kz);
+                        // one 32-bit byte offset per access (uniform base + 32-bit offset: no 64-bit pointer pairs in the BIG kernel)
+                        const uint32_t nb = cur * K_NODE_BYTES;
+                        const float* px = reinterpret_cast<const float*>(nodes + (nb + kx));
+                        const float* py = reinterpret_cast<const float*>(nodes + (nb + ky));
+                        const float* pz = reinterpret_cast<const float*>(nodes + (nb + kz));
                         const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
                         const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
                         const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
-                        const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS], refs_hi = BIG ? reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS + 1u] : 0u;
+                        const uint32_t* pr = reinterpret_cast<const uint32_t*>(nodes + nb);
+                        const uint32_t refs = pr[RT_NODE_REFS], refs_hi = BIG ? pr[RT_NODE_REFS + 1u] : 0u;
                         const uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
                         float tl, tr;
                         const bool hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, inv_lo, rec_t, tl);
@@ -547,8 +551,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                             const rt_material& mg = p.scene.mats[mat_bits & RT_MAT_INDEX_MASK];
                             albedo = checker_value(albedo, mk3(mg.albedo2[0], mg.albedo2[1], mg.albedo2[2]), mparam, hit_p);
                         }
-                        if (EXT && mtype == RT_MAT_LAMBERTIAN_NOISE) albedo = noise_value(p.scene.perlin, albedo, mparam, hit_p);
-                        if (EXT && mtype == RT_MAT_LAMBERTIAN_IMAGE) albedo = image_value(p.scene.image, p.scene.image_w, p.scene.image_h, normal);
+                        if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_NOISE) albedo = noise_value(p.scene.perlin, albedo, mparam, hit_p);
+                        if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_IMAGE) albedo = image_value(p.scene.image, p.scene.image_w, p.scene.image_h, normal);
                     }
                 }
                 RT_PT(13);
