@@ -151,6 +151,21 @@ public:
     explicit DiffuseLightAbstract(glm::vec3 emit) : GeometryDependantMaterial<G>(RT_MAT_DIFFUSE_LIGHT, emit, 0.0f) {}
 };
 
+// isotropic / lambertian(noise_texture) / lambertian(image_texture) of "The Next Week" — extensions, not in the reference.
+// A Sphere made of IsotropicAbstract is a constant_medium of that density bounded by the sphere.
+template <typename G> class IsotropicAbstract : public GeometryDependantMaterial<G> {
+public:
+    IsotropicAbstract(glm::vec3 albedo, float density) : GeometryDependantMaterial<G>(RT_MAT_ISOTROPIC, albedo, density) {}
+};
+template <typename G> class NoiseTextureAbstract : public GeometryDependantMaterial<G> {   // needs Factory::SetPerlin
+public:
+    explicit NoiseTextureAbstract(float scale, glm::vec3 albedo = glm::vec3(0.5f)) : GeometryDependantMaterial<G>(RT_MAT_LAMBERTIAN_NOISE, albedo, scale) {}
+};
+template <typename G> class ImageTextureAbstract : public GeometryDependantMaterial<G> {   // needs Factory::SetImage; spheres only
+public:
+    ImageTextureAbstract() : GeometryDependantMaterial<G>(RT_MAT_LAMBERTIAN_IMAGE, glm::vec3(1.0f), 0.0f) {}
+};
+
 // newOnDevice<T>(args...) (cuda_utils.cuh:16-23): the reference cudaMallocs one object and runs a <<<1,1>>>
 // placement-new kernel + cudaDeviceSynchronize per call; here it is a host allocation of the descriptor.
 template <typename T, typename... Args> inline T* newOnDevice(const Args&... args) { return new T(args...); }
@@ -253,6 +268,8 @@ public:
         }
         return prim;
     }
+    void perlin(uint64_t seed) { check(rt_scene_set_perlin(s_, seed), "rt_scene_set_perlin"); }
+    void image(uint32_t w, uint32_t h, const uint8_t* rgb) { check(rt_scene_set_image(s_, w, h, rgb), "rt_scene_set_image"); }
     void background(const Background& b) {
         float c[3] = {b.color[0], b.color[1], b.color[2]};
         check(rt_scene_set_background(s_, b.constant ? 1u : 0u, c), "rt_scene_set_background");
@@ -366,8 +383,14 @@ class BVH_Handle::Factory {
     std::vector<std::tuple<aabb, const Hittable*>>& arr;
     std::unique_ptr<rt06::SceneBuilder> builder_;
     Background background_;
+    bool has_perlin_ = false;
+    uint64_t perlin_seed_ = 0;
+    uint32_t image_w_ = 0, image_h_ = 0;
+    std::vector<uint8_t> image_;
     void collect() {
         builder_.reset(new rt06::SceneBuilder());
+        if (has_perlin_) builder_->perlin(perlin_seed_);
+        if (!image_.empty()) builder_->image(image_w_, image_h_, image_.data());
         for (auto& e : arr) builder_->primitive(std::get<1>(e));
         builder_->background(background_);
     }
@@ -375,6 +398,8 @@ class BVH_Handle::Factory {
 public:
     explicit Factory(std::vector<std::tuple<aabb, const Hittable*>>& a) : arr(a) {}
     void SetBackground(glm::vec3 color) { background_.constant = true; background_.color = color; }  // extension; call before Build*
+    void SetPerlin(uint64_t seed) { has_perlin_ = true; perlin_seed_ = seed; }                       // extension: noise tables of the world
+    void SetImage(uint32_t w, uint32_t h, const uint8_t* rgb) { image_w_ = w; image_h_ = h; image_.assign(rgb, rgb + (size_t)w * h * 3); }
     void BuildBVH_TopDown() { collect(); rt06::check(rt_scene_build_bvh_topdown(builder_->get()), "BuildBVH_TopDown"); }  // _build_bvh_rec1
     void BuildBVH_TopDown_SAH() { collect(); rt06::check(rt_scene_build_bvh_sah(builder_->get()), "BuildBVH_TopDown_SAH"); }  // _build_bvh_rec2 (the #else branch, BVH.cu:168-172)
     void BuildBVH_BottomUp() { collect(); rt06::check(rt_scene_build_bvh_bottomup(builder_->get()), "BuildBVH_BottomUp"); }
