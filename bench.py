@@ -31,22 +31,56 @@ import __graft_entry__ as G  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+# BASELINE.json configs: the headline (default) is configs[1]; the others are parity-test cases that can be timed with
+# the same harness.  (product scene ctor, camera ctor + args, oracle scene ctor, oracle camera ctor, W, H, spp, depth, text)
+WORKLOADS = {
+    "book1_final": ("book1_final", "DefocusBlurCamera", ((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, None, 0.1, 10.0), "camera_defocus",
+                    1200, 800, 500, 50, "Book-1 final random-spheres scene (488 spheres, 975-node BVH)", "DefocusBlurCamera vfov 20 aperture 0.1"),
+    "book2_moving": ("book2_moving", "MotionBlurCamera", ((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, None, 0.0, 1.0), "camera_motion",
+                     800, 800, 1000, 50, "Book-2 moving-spheres scene (488 spheres, 975-node BVH)", "MotionBlurCamera vfov 20 shutter 0..1"),
+    "cornell_box": ("cornell_box", "PinholeCamera", ((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, None), "camera_pinhole",
+                    600, 600, 5000, 50, "Cornell box of The Next Week (18 quads, area light; not in the reference)", "PinholeCamera vfov 40"),
+    "book2_final": ("book2_final", "MotionBlurCamera", ((478, 278, -600), (278, 278, 0), (0, 1, 0), 40.0, None, 0.0, 1.0), "camera_motion",
+                    800, 800, 1000, 40, "final scene of The Next Week (2401 quads, 1008 spheres, media, Perlin, image texture; not in the reference)",
+                    "MotionBlurCamera vfov 40 shutter 0..1"),
+}
+
+
+def make_workload(args, mod, oracle=False):
+    """(scene, camera) of the selected workload through the product package (oracle=False) or the CPU oracle bindings."""
+    wl = WORKLOADS[args.workload]
+    cam_args = tuple(args.width / args.height if a is None else a for a in wl[2])
+    if oracle:
+        scene = getattr(mod.Scene, wl[0])() if wl[0] == "cornell_box" else getattr(mod.Scene, wl[0])(args.seed)
+        return scene, getattr(mod, wl[3])(*cam_args)
+    scene = getattr(mod.Scene, wl[0])() if wl[0] == "cornell_box" else getattr(mod.Scene, wl[0])(args.seed)
+    return scene, getattr(mod, wl[1])(*cam_args)
+
+
 def parse():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="book1_final", choices=sorted(WORKLOADS),
+                    help="book1_final = BASELINE configs[1], the headline (default); the others time configs[2..4] with the same harness")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=1200)
-    ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--spp", type=int, default=500)
-    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--width", type=int, default=None, help="default: the workload's (1200 for the headline)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--seed", type=int, default=1984)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    wl = WORKLOADS[a.workload]
+    a.width = a.width or wl[4]
+    a.height = a.height or wl[5]
+    a.spp = a.spp or wl[6]
+    a.depth = a.depth or wl[7]
+    return a
 
 
 def host_cores():
@@ -111,8 +145,7 @@ def count_leg(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     W, H = args.width, args.height
-    oscene = O.Scene.book1_final(args.seed)
-    ocam = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    oscene, ocam = make_workload(args, O, oracle=True)
     _, cnt = O.render(oscene.world, ocam, W, H, 1, args.depth, args.seed, threads=host_cores())
     n = float(cnt.samples)
     return {"box_tests": cnt.box_tests / n, "leaf_tests": cnt.leaf_tests / n, "shaded_hits": cnt.shaded_hits / n,
@@ -126,8 +159,7 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
     import _oracle as O
     cores = host_cores()
     W, H = args.width, args.height
-    oscene = O.Scene.book1_final(args.seed)
-    ocam = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    oscene, ocam = make_workload(args, O, oracle=True)
     # calibrate on 1 spp, then size the sample for ~cpu_seconds of wall time
     t = time.perf_counter()
     O.render(oscene.world, ocam, W, H, 1, args.depth, args.seed, threads=cores)
@@ -140,7 +172,7 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
     counts = {"box_tests": cnt.box_tests / n, "leaf_tests": cnt.leaf_tests / n, "shaded_hits": cnt.shaded_hits / n,
               "rays": cnt.rays / n, "rng_draws": cnt.rng_draws / n}
     base = {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{W}x{H}x{spp}spp Book-1 final, depth {args.depth}, seed {args.seed}, {dt:.1f}s wall, "
+            "sample": f"{W}x{H}x{spp}spp {args.workload}, depth {args.depth}, seed {args.seed}, {dt:.1f}s wall, "
                       f"gcc -O2 -ffp-contract=off, pthreads over rows"}
     parity = None
     if gpu_image_fn is not None:
@@ -176,8 +208,7 @@ def main():
 
     pkg = G.load_package()
     W, H, spp = args.width, args.height, args.spp
-    scene = pkg.Scene.book1_final(args.seed)
-    cam = pkg.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    scene, cam = make_workload(args, pkg)
     world = scene.getWorldPtr()
     r = pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank,
                                   rank=rank, world_size=world_size, variant=args.variant)
@@ -240,12 +271,12 @@ def main():
             base, counts, parity = cpu_leg(args, pkg, scene, cam, None if args.no_parity else gpu_image)
         value = total_samples * args.steps / elapsed / 1e6
         out = {
-            "metric": "Msamples/sec (WxHxspp) on Book-1 final scene",
+            "metric": "Msamples/sec (WxHxspp) on Book-1 final scene" if args.workload == "book1_final" else f"Msamples/sec (WxHxspp) on {args.workload}",
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Book-1 final random-spheres scene (488 spheres, 975-node BVH), {W}x{H}, {spp} spp, "
-                                   f"max_depth {args.depth}, seed {args.seed}, DefocusBlurCamera vfov 20 aperture 0.1",
+            "config": {"workload": f"{WORKLOADS[args.workload][8]}, {W}x{H}, {spp} spp, "
+                                   f"max_depth {args.depth}, seed {args.seed}, {WORKLOADS[args.workload][9]}",
                        "parallelism": f"tile-shard x{world_size} + 1 RCCL gather" if world_size > 1 else "single GPU",
                        "kernel_variant": args.variant},
             "kernel_ms_per_step_rank0": round(kernel_ms, 3),
@@ -256,7 +287,7 @@ def main():
             bytes_per_sample = 32.0 * counts["box_tests"] + 16.0 * counts["leaf_tests"] + 16.0 * counts["shaded_hits"] + 16.0 / spp
             launch_samples = total_samples / world_size
             achieved = bytes_per_sample * launch_samples / (kernel_ms * 1e-3) / 1e9
-            default_cfg = (W, H, spp, args.depth, args.variant, world_size) == (1200, 800, 500, 50, 0, 1)
+            default_cfg = (args.workload, W, H, spp, args.depth, args.variant, world_size) == ("book1_final", 1200, 800, 500, 50, 0, 1)
             traffic, traffic_src = profiled_traffic("render_kernel_stream") if default_cfg else (None, None)
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
