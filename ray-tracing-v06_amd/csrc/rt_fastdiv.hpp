@@ -1,10 +1,12 @@
-// rt_fastdiv.hpp — correctly rounded fp32 division in 5 instructions, for the BVH box tests.
+// rt_fastdiv.hpp — correctly rounded fp32 division in 5 (one reciprocal word) or 4 (two words) instructions, and the
+// correctly rounded reciprocal in 3, for the BVH box tests.
 //
 // aabb::intersects (rt_engine/geometry/aabb.cuh:30-31) divides six plane offsets by the ray direction
 // for EVERY box: (min - o) / d, (max - o) / d.  An IEEE-correct fp32 `/` costs ~11 instructions on
 // gfx950 (v_div_scale x2, v_rcp, 4-5 v_fma, v_div_fmas, v_div_fixup), i.e. ~130 of the ~300
 // instructions of one inner-node visit.  The direction is constant along a ray, so r = RN(1/d) is
-// computed once per ray with a true division and each quotient is then recovered EXACTLY:
+// computed once per ray (rcp_exact_regular) and each quotient is then recovered EXACTLY (the hot loop uses the 4-instruction
+// form fast_div_exact4 further down; this one serves the root box and the filtered variant):
 //
 //      q0 = RN(n * r)                 |q0 - n/d| <= ~2 ulp          (two roundings)
 //      e0 = fma(-q0, d, n)            residual of q0

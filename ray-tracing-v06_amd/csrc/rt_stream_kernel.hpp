@@ -17,10 +17,15 @@
 //    only WHICH lanes run WHICH phase together: the wave runs "inner node" steps while most lanes sit at
 //    an inner node, services lanes that reached a leaf or finished a trace when enough have piled up
 //    (wave ballots), and never lets one lane's long traversal hold 63 finished ones.
-//  * the scene is staged once per workgroup into LDS (coalesced 16-B loads of one packed blob): 64-B
-//    "wide" inner nodes that carry BOTH child boxes and child references (so a visit is one address, four
-//    ds_read_b128, and leaves need no node fetch at all), 16-B sphere records and 16-B (centre1,
-//    material) records.  The per-lane traversal stack lives in LDS too, sized from the tree's depth.
+//  * the scene is staged once per workgroup into LDS (coalesced 16-B loads of one packed blob): 76-B
+//    "wide" inner nodes that carry BOTH child boxes as (min, max, min) triples and both child references (so a visit
+//    is one address and leaves need no node fetch at all; the triples turn the slab test's per-axis min/max into a
+//    per-ray address offset), 16-B sphere records and 16-B (centre1, material) records.  The per-lane traversal stack
+//    lives in LDS too, sized from the tree's depth.  Worlds that do not fit keep their records in global memory / L2
+//    (BIG instantiation, 32-bit references).
+//  * gfx950 issues fp32 add/mul/fma and simple integer ops in 2 cycles per wave, compares / selects / min / max in 4,
+//    and scalar instructions are NOT hidden behind the vector issue (tools/bench_valu_issue.hip): the hot loop is
+//    straight-line code built from the cheap class, one compare per phase test, exact division without dividing.
 //  * the counter-based RNG keeps no state in memory; every sample writes its radiance (12 B) to an HBM
 //    sample buffer laid out [pixel-block][sample][64 pixels], and `resolve_kernel` adds them IN SAMPLE
 //    ORDER per pixel — the same order as the reference's `radiance +=` loop — so the framebuffer is
@@ -124,8 +129,8 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 
 // A lane's status lives in `cur` alone (compares and selects are half-rate on gfx950; one register, one compare):
 //   cur <  RT_REF_IRR              at an inner node, ray in the fast-division class            } tracing
-//   cur <  RT_REF_LEAF             at an inner node (marked RT_REF_IRR: ray outside the class) }  (RT_CUR_TRACING(cur))
-//   cur <  RT_CUR_SHADE            at a leaf: RT_REF_LEAF | code (code <= 0x7ffe)              }
+//   cur <  RT_REF_LEAF             at an inner node (marked RT_REF_IRR: ray outside the class) }  (cur < K_SHADE)
+//   cur <  K_SHADE                 at a leaf: RT_REF_LEAF | code (code <= 0x7ffe)              }
 //   cur == K_SHADE                 trace finished, waiting for the shade phase
 //   cur == K_NEED                  path finished, waiting for a new sample
 //   cur == K_OFF                   no samples left
@@ -135,9 +140,9 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 // values 0xfffffffc .. 0xffffffff.  "Tracing" is `cur < K_SHADE` either way.
 
 // EXACT = true : box tests use aabb_intersects() verbatim (IEEE division, GLM min/max).
-// EXACT = false: rays classified "regular" use the 5-instruction correctly-rounded division and IEEE
-//                min/max (rt_fastdiv.hpp) — identical decisions, proven + exhaustively verified; other
-//                rays take the verbatim path lane by lane.
+// EXACT = false: rays classified "regular" use the 4-instruction correctly-rounded division (two-word reciprocal) and
+//                near/far plane selection by address (rt_fastdiv.hpp) — identical decisions, proven + exhaustively
+//                verified; other rays carry marked references and are stepped by a verbatim loop.
 // FILTER = true (variant 4, experimental): decide the two box tests of a visit from one-multiply plane
 //                parameters with a safety margin (box_pair_filtered) and fall back to exact quotients only
 //                for near-ties; sound and bit-identical, but not faster yet because ~1.5 % of visits are ties.
