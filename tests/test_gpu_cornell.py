@@ -328,3 +328,34 @@ def test_book2_final_scene_renders_bit_exact(p):
     ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
     assert bits_equal(img, ref), mismatch_report(img, ref)
     assert ref[..., :3].max() == 1.0 and ref[..., :3].mean() > 0.02
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE configs[3] / [4] at (near) full size through a sparse exact check: the oracle renders only the sampled pixels
+# ------------------------------------------------------------------------------------------------
+def _sparse_full_size(p, which, W, H, spp, depth, n_px, seed):
+    s = config_scene(p, which)
+    cam = config_cameras(p, which, W, H)
+    w = s.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    ms = r.last_kernel_ms()
+    r.close()
+    rng = np.random.default_rng(seed)
+    gids = rng.integers(0, W * H, n_px).astype(np.uint32)
+    exp = O.render_pixels(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth, gids)
+    got = img.reshape(-1, 4)[gids]
+    assert np.all(img[..., 3] == 1.0) and np.all(np.isfinite(img))
+    assert bits_equal(got, exp), mismatch_report(got, exp)
+    print(f"{which} {W}x{H}x{spp}: {W * H * spp / ms / 1e3:.1f} Msamples/s ({ms:.1f} ms), {n_px} pixels bit-identical to the oracle")
+
+
+def test_full_size_cornell_box_sparse_parity(p):
+    """configs[3]: 600x600, 5000 spp (1.8e9 samples on one GPU; the config shards it over 4)."""
+    _sparse_full_size(p, "cornell_box", 600, 600, 5000, 50, 24, 13)
+
+
+def test_book2_final_at_bench_size_sparse_parity(p):
+    """configs[4] scene at the size bench.py --workload book2_final times (800x800, 200 spp, depth 40)."""
+    _sparse_full_size(p, "book2_final", 800, 800, 200, 40, 48, 14)
