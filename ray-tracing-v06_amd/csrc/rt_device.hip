@@ -53,14 +53,20 @@ struct DevBuf {
 // one wide node of the LDS image (layout: rt_stream_kernel.hpp): per child box and axis the triple (min, max, min)
 static void write_wide_node(uint4* blob, bool big, uint32_t index, const float lmin[3], const float lmax[3], const float rmin[3],
                             const float rmax[3], uint32_t lref, uint32_t rref) {
-    uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * (big ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS);
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    if (big) {  // one 64-byte line: [lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right - -]
+        uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * RT_NODE_DWORDS_BIG;
+        const float v[12] = {lmin[0], lmin[1], lmin[2], lmax[0], lmax[1], lmax[2], rmin[0], rmin[1], rmin[2], rmax[0], rmax[1], rmax[2]};
+        for (int k = 0; k < 12; k++) d[k] = bits(v[k]);
+        d[12] = lref; d[13] = rref; d[14] = 0; d[15] = 0;
+        return;
+    }
+    uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * RT_NODE_DWORDS;
     for (int k = 0; k < 3; k++) {
         d[3 * k + 0] = bits(lmin[k]); d[3 * k + 1] = bits(lmax[k]); d[3 * k + 2] = bits(lmin[k]);
         d[9 + 3 * k + 0] = bits(rmin[k]); d[9 + 3 * k + 1] = bits(rmax[k]); d[9 + 3 * k + 2] = bits(rmin[k]);
     }
-    if (big) { d[RT_NODE_REFS] = lref; d[RT_NODE_REFS + 1] = rref; }
-    else d[RT_NODE_REFS] = (lref & 0xffffu) | (rref << 16);
+    d[RT_NODE_REFS] = (lref & 0xffffu) | (rref << 16);
 }
 
 struct DeviceScene {

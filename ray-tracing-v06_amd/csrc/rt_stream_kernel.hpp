@@ -64,13 +64,15 @@
 #define RT_NODE_DWORDS 19u
 #define RT_NODE_BYTES (RT_NODE_DWORDS * 4u)
 #define RT_NODE_REFS 18u
-// BIG scenes (the image does not fit the LDS, or has 2^14 inner nodes / 2^15 leaf codes or more): the same records are
-// read from global memory (they stay L2-resident) and references are 32 bits wide — a wide node is 20 dwords with the
-// left / right reference in dwords 18 / 19, bit 31 marks a leaf, bit 30 a ray outside the fast class; the per-lane
-// stacks (32-bit entries) are all that lives in the LDS.
+// BIG scenes (the image does not fit the LDS, or has 2^14 inner nodes / 2^15 leaf codes or more): the records are read
+// from global memory (they stay L2-resident) and references are 32 bits wide (bit 31 marks a leaf, bit 30 a ray outside
+// the fast class); the per-lane stacks (32-bit entries) are all that lives in the LDS.  That path is bound by the L1's
+// tag-lookup rate — 64 lanes reading 64 different nodes cost ~20 lookups per load instruction (PMC) — not by the vector
+// issue, so its wide node is ONE 64-byte line read with four 16-byte loads, [lmin.xyz lmax.x | lmax.yz rmin.xy |
+// rmin.z rmax.xyz | left, right, -, -], and near / far planes are picked with selects instead of by address.
 #define RT_REF_LEAF_BIG 0x80000000u
 #define RT_REF_IRR_BIG 0x40000000u
-#define RT_NODE_DWORDS_BIG 20u
+#define RT_NODE_DWORDS_BIG 16u
 // number of 16-B units the node region of `n` wide nodes occupies in the blob
 #define RT_NODES_VEC4(n, big) (((n) * ((big) ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) + 3u) / 4u)
 
@@ -139,6 +141,42 @@ __device__ __forceinline__ bool block_origin(const TileMap& tm, uint32_t blk, ui
 // the stack; leaf codes stop at 0x7ffe), NEED 0x20000, OFF 0x30000, START 0x40000; 32-bit references (BIG): the top four
 // values 0xfffffffc .. 0xffffffff.  "Tracing" is `cur < K_SHADE` either way.
 
+// The (near, far) plane pairs of both child boxes of wide node `idx` and its two child references.  kx/ky/kz: 0 where the
+// ray direction component is >= 0 (near = box min) or the ray is outside the fast class, 4 where it is negative.
+struct WideNodeData {
+    float lnx, lny, lnz, lfx, lfy, lfz, rnx, rny, rnz, rfx, rfy, rfz;
+    uint32_t left, right;
+};
+template <bool BIG>
+__device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, uint32_t idx, uint32_t kx, uint32_t ky, uint32_t kz) {
+    WideNodeData n;
+    if (BIG) {
+        const float4* q = reinterpret_cast<const float4*>(nodes + idx * (RT_NODE_DWORDS_BIG * 4u));
+        const float4 a = q[0], b = q[1], c = q[2];
+        const uint4 r = reinterpret_cast<const uint4*>(q)[3];
+        const bool sx = kx != 0u, sy = ky != 0u, sz = kz != 0u;
+        n.lnx = sx ? a.w : a.x; n.lfx = sx ? a.x : a.w;
+        n.lny = sy ? b.x : a.y; n.lfy = sy ? a.y : b.x;
+        n.lnz = sz ? b.y : a.z; n.lfz = sz ? a.z : b.y;
+        n.rnx = sx ? c.y : b.z; n.rfx = sx ? b.z : c.y;
+        n.rny = sy ? c.z : b.w; n.rfy = sy ? b.w : c.z;
+        n.rnz = sz ? c.w : c.x; n.rfz = sz ? c.x : c.w;
+        n.left = r.x; n.right = r.y;
+    } else {
+        // one 32-bit byte offset per access: (near, far) are consecutive dwords of the (min, max, min) triples
+        const uint32_t nb = idx * RT_NODE_BYTES;
+        const float* px = reinterpret_cast<const float*>(nodes + (nb + kx));
+        const float* py = reinterpret_cast<const float*>(nodes + (nb + ky));
+        const float* pz = reinterpret_cast<const float*>(nodes + (nb + kz));
+        n.lnx = px[0]; n.lfx = px[1]; n.rnx = px[9]; n.rfx = px[10];
+        n.lny = py[3]; n.lfy = py[4]; n.rny = py[12]; n.rfy = py[13];
+        n.lnz = pz[6]; n.lfz = pz[7]; n.rnz = pz[15]; n.rfz = pz[16];
+        const uint32_t refs = reinterpret_cast<const uint32_t*>(nodes + nb)[RT_NODE_REFS];
+        n.left = refs & 0xffffu; n.right = refs >> 16;
+    }
+    return n;
+}
+
 // EXACT = true : box tests use aabb_intersects() verbatim (IEEE division, GLM min/max).
 // EXACT = false: rays classified "regular" use the 4-instruction correctly-rounded division (two-word reciprocal) and
 //                near/far plane selection by address (rt_fastdiv.hpp) — identical decisions, proven + exhaustively
@@ -167,7 +205,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     constexpr uint32_t K_LEAF = BIG ? RT_REF_LEAF_BIG : RT_REF_LEAF, K_IRR = BIG ? RT_REF_IRR_BIG : RT_REF_IRR;
     constexpr uint32_t K_SHADE = BIG ? 0xfffffffcu : 0xffffu, K_NEED = BIG ? 0xfffffffdu : 0x20000u;
     constexpr uint32_t K_OFF = BIG ? 0xfffffffeu : 0x30000u, K_START = BIG ? 0xffffffffu : 0x40000u;
-    constexpr uint32_t K_NODE_BYTES = (BIG ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) * 4u;
     static_assert(!BIG || WORLD == RT_WORLD_BVH, "BIG scenes are BVH worlds");
 
     // ---- the scene: staged into the LDS with coalesced 16-B loads, or (BIG) left in global memory / L2 -------------
@@ -282,20 +319,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 uint32_t n_inner_lanes;
                 do {
                     if (at_inner) {
-                        // one 32-bit byte offset per access (uniform base + 32-bit offset: no 64-bit pointer pairs in the BIG kernel)
-                        const uint32_t nb = cur * K_NODE_BYTES;
-                        const float* px = reinterpret_cast<const float*>(nodes + (nb + kx));
-                        const float* py = reinterpret_cast<const float*>(nodes + (nb + ky));
-                        const float* pz = reinterpret_cast<const float*>(nodes + (nb + kz));
-                        const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
-                        const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
-                        const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
-                        const uint32_t* pr = reinterpret_cast<const uint32_t*>(nodes + nb);
-                        const uint32_t refs = pr[RT_NODE_REFS], refs_hi = BIG ? pr[RT_NODE_REFS + 1u] : 0u;
-                        const uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
+                        const WideNodeData nd = fetch_wide_node<BIG>(nodes, cur, kx, ky, kz);
+                        const uint32_t left_idx = nd.left, right_idx = nd.right;
                         float tl, tr;
-                        const bool hl = slab_near_far_regular(lnx, lny, lnz, lfx, lfy, lfz, ray, inv_d, inv_lo, rec_t, tl);
-                        const bool hr = slab_near_far_regular(rnx, rny, rnz, rfx, rfy, rfz, ray, inv_d, inv_lo, rec_t, tr);
+                        const bool hl = slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
+                        const bool hr = slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
                         // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".
@@ -320,14 +348,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     const bool at_irr = (cur & (K_LEAF | K_IRR)) == K_IRR;
                     if (__ballot(at_irr) == 0ull) break;
                     if (at_irr) {
-                        const float* nf = reinterpret_cast<const float*>(nodes + (cur & (K_IRR - 1u)) * K_NODE_BYTES);
-                        const uint32_t refs = reinterpret_cast<const uint32_t*>(nf)[RT_NODE_REFS], refs_hi = BIG ? reinterpret_cast<const uint32_t*>(nf)[RT_NODE_REFS + 1u] : 0u;
-                        uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
+                        const WideNodeData nd = fetch_wide_node<BIG>(nodes, cur & (K_IRR - 1u), 0u, 0u, 0u);   // near = min, far = max
+                        uint32_t left_idx = nd.left, right_idx = nd.right;
                         if (left_idx < K_LEAF) left_idx |= K_IRR;     // inner references stay marked all the way down
                         if (right_idx < K_LEAF) right_idx |= K_IRR;
                         float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
-                        const bool hl = aabb_intersects(mk3(nf[0], nf[3], nf[6]), mk3(nf[1], nf[4], nf[7]), ray, rec_t, left_dist);
-                        const bool hr = aabb_intersects(mk3(nf[9], nf[12], nf[15]), mk3(nf[10], nf[13], nf[16]), ray, rec_t, right_dist);
+                        const bool hl = aabb_intersects(mk3(nd.lnx, nd.lny, nd.lnz), mk3(nd.lfx, nd.lfy, nd.lfz), ray, rec_t, left_dist);
+                        const bool hr = aabb_intersects(mk3(nd.rnx, nd.rny, nd.rnz), mk3(nd.rfx, nd.rfy, nd.rfz), ray, rec_t, right_dist);
                         const bool swap_lr = left_dist > right_dist;
                         if (hl && hr) {
                             *sp = (ref_t)(swap_lr ? left_idx : right_idx);
@@ -345,16 +372,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             uint64_t m_inner = __ballot(at_inner);
             while (m_inner != 0ull) {
                 if (at_inner) {
-                    const char* nb = nodes + cur * K_NODE_BYTES;
-                    // (near, far) plane pairs of the three axes; kx/ky/kz are 0 in these kernels: near == box min, far == box max
-                    const float* px = reinterpret_cast<const float*>(nb + kx);
-                    const float* py = reinterpret_cast<const float*>(nb + ky);
-                    const float* pz = reinterpret_cast<const float*>(nb + kz);
-                    const float lnx = px[0], lfx = px[1], rnx = px[9], rfx = px[10];
-                    const float lny = py[3], lfy = py[4], rny = py[12], rfy = py[13];
-                    const float lnz = pz[6], lfz = pz[7], rnz = pz[15], rfz = pz[16];
-                    const uint32_t refs = reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS], refs_hi = BIG ? reinterpret_cast<const uint32_t*>(nb)[RT_NODE_REFS + 1u] : 0u;
-                    const uint32_t left_idx = BIG ? refs : (refs & 0xffffu), right_idx = BIG ? refs_hi : (refs >> 16);
+                    // kx/ky/kz are 0 in these kernels: near == box min, far == box max
+                    const WideNodeData nd = fetch_wide_node<BIG>(nodes, cur, 0u, 0u, 0u);
+                    const float lnx = nd.lnx, lny = nd.lny, lnz = nd.lnz, lfx = nd.lfx, lfy = nd.lfy, lfz = nd.lfz;
+                    const float rnx = nd.rnx, rny = nd.rny, rnz = nd.rnz, rfx = nd.rfx, rfy = nd.rfy, rfz = nd.rfz;
+                    const uint32_t left_idx = nd.left, right_idx = nd.right;
                     if (WORLD == RT_WORLD_NODE_TREE) {
                         // bvh_node::ClosestIntersection (bvh_node.cuh:19-24): own box, then left subtree, then right
                         float d_own;
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                                 // a comparison too close to call (~1e-6 of visits): redo the visit with exact quotients.
                                 // The node is re-read (volatile) so that the common path need not keep 12 box
                                 // coordinates alive across the filter.
-                                const volatile float* vn = reinterpret_cast<const volatile float*>(nb);
+                                const volatile float* vn = reinterpret_cast<const volatile float*>(nodes + cur * RT_NODE_BYTES);   // FILTER kernels are LDS-resident
                                 float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
                                 hl = aabb_intersects_regular(mk3(vn[0], vn[3], vn[6]), mk3(vn[1], vn[4], vn[7]), ray, inv_d, rec_t, left_dist);
                                 hr = aabb_intersects_regular(mk3(vn[9], vn[12], vn[15]), mk3(vn[10], vn[13], vn[16]), ray, inv_d, rec_t, right_dist);
