@@ -100,7 +100,17 @@ struct DeviceScene {
         // wide nodes: BVH -> one per inner node, holding BOTH child boxes; bvh_node tree -> one per node, holding its OWN box
         std::vector<int32_t> wide_of(w->n_nodes, -1);
         uint32_t n_inner = 0;
-        if (w->kind == RT_WORLD_BVH) {
+        if (w->kind == RT_WORLD_BVH && big) {
+            // breadth-first numbering: the first n_top wide nodes are the top of the tree, which the BIG kernel keeps in the LDS
+            std::vector<int32_t> queue;
+            if (w->nodes[w->root].left != -1) queue.push_back(w->root);
+            for (size_t h = 0; h < queue.size(); h++) {
+                const rt_bvh_node& n = w->nodes[queue[h]];
+                wide_of[queue[h]] = (int32_t)n_inner++;
+                if (w->nodes[n.left].left != -1) queue.push_back(n.left);
+                if (w->nodes[n.right].left != -1) queue.push_back(n.right);
+            }
+        } else if (w->kind == RT_WORLD_BVH) {
             for (uint32_t i = 0; i < w->n_nodes; i++)
                 if (w->nodes[i].left != -1) wide_of[i] = (int32_t)n_inner++;
         } else if (w->kind == RT_WORLD_NODE_TREE) {
@@ -315,6 +325,7 @@ struct rt_renderer {
     uint32_t pass_spp = 0;       // samples per pixel per pass
     uint32_t n_cus = 0;
     uint32_t stream_lds_bytes = 0;
+    uint32_t n_top = 0;  // BIG kernels: wide nodes (breadth-first order) staged in the LDS
     uint32_t stream_block = RT_STREAM_BLOCK;
     uint32_t stream_blocks_per_cu = 0;
     uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
@@ -342,9 +353,15 @@ struct rt_renderer {
                 int v = std::atoi(env);
                 if (v == 512 || v == 768 || v == 1024) stream_block = (uint32_t)v;
             }
-            if (scene.big) {  // only the per-lane stacks (32-bit entries) live in the LDS
+            if (scene.big) {  // the per-lane stacks (32-bit entries) and, in what two workgroups per CU leave free, the top of the tree
                 stream_block = RT_STREAM_BLOCK;
-                stream_lds_bytes = (stream_block * scene.packed.stack_cap * 4u + 15u) & ~15u;
+                const uint32_t stacks = (stream_block * scene.packed.stack_cap * 4u + 63u) & ~63u;
+                const uint32_t budget = stacks + 4096u <= lds_per_cu / 2u ? lds_per_cu / 2u : lds_per_cu;
+                uint32_t top_bytes = budget > stacks ? budget - stacks : 0u;
+                top_bytes = std::min(top_bytes & ~63u, scene.packed.n_inner * (RT_NODE_DWORDS_BIG * 4u));
+                if (const char* env = std::getenv("RT06_TOP_NODES")) top_bytes = std::min(top_bytes, (uint32_t)std::atoi(env) * (RT_NODE_DWORDS_BIG * 4u));
+                n_top = top_bytes / (RT_NODE_DWORDS_BIG * 4u);
+                stream_lds_bytes = top_bytes + stacks;
             } else {
                 stream_lds_bytes = scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u;
                 stream_lds_bytes = (stream_lds_bytes + 15u) & ~15u;
@@ -435,6 +452,7 @@ struct rt_renderer {
         p.cam = cam;
         p.tm = tm;
         p.scene = scene.packed;
+        p.scene.n_top = scene.big ? n_top : 0u;
         p.samples = samples.as<float>();
         p.work_counter = work_counter.as<uint32_t>();
         p.inner_keep = tune[0] ? tune[0] : 1u; p.shade_min = tune[1]; p.leaf_min = tune[2];

@@ -92,6 +92,7 @@ struct PackedSceneRef {
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
     uint32_t n_inner, n_codes, n_prims;
+    uint32_t n_top;          // BIG: the first n_top wide nodes (breadth-first order = the top of the tree) are staged in the LDS
     const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
     const rt_perlin* perlin; // EXT: noise tables / image of the two textured materials (global memory), or null
     const uint8_t* image;
@@ -147,13 +148,24 @@ struct WideNodeData {
     float lnx, lny, lnz, lfx, lfy, lfz, rnx, rny, rnz, rfx, rfy, rfz;
     uint32_t left, right;
 };
+// BIG: nodes below n_top come from their LDS copy (`top`), the others from global memory — the global path is bound by
+// the L1's tag lookups, which only the lanes that really go to memory consume.
 template <bool BIG>
-__device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, uint32_t idx, uint32_t kx, uint32_t ky, uint32_t kz) {
+__device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const uint4* top, uint32_t n_top, uint32_t idx,
+                                                        uint32_t kx, uint32_t ky, uint32_t kz) {
     WideNodeData n;
     if (BIG) {
-        const float4* q = reinterpret_cast<const float4*>(nodes + idx * (RT_NODE_DWORDS_BIG * 4u));
-        const float4 a = q[0], b = q[1], c = q[2];
-        const uint4 r = reinterpret_cast<const uint4*>(q)[3];
+        float4 a, b, c;
+        uint4 r;
+        if (idx < n_top) {
+            const float4* q = reinterpret_cast<const float4*>(top + idx * (RT_NODE_DWORDS_BIG / 4u));
+            a = q[0]; b = q[1]; c = q[2];
+            r = reinterpret_cast<const uint4*>(q)[3];
+        } else {
+            const float4* q = reinterpret_cast<const float4*>(nodes + idx * (RT_NODE_DWORDS_BIG * 4u));
+            a = q[0]; b = q[1]; c = q[2];
+            r = reinterpret_cast<const uint4*>(q)[3];
+        }
         const bool sx = kx != 0u, sy = ky != 0u, sz = kz != 0u;
         n.lnx = sx ? a.w : a.x; n.lfx = sx ? a.x : a.w;
         n.lny = sy ? b.x : a.y; n.lfy = sy ? a.y : b.x;
@@ -211,6 +223,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     const uint4* scene_base;
     if (BIG) {
         scene_base = p.scene.blob;
+        for (uint32_t i = tid; i < p.scene.n_top * (RT_NODE_DWORDS_BIG / 4u); i += BLOCK) lds[i] = p.scene.blob[i];   // the top of the tree
+        __syncthreads();
     } else {
         for (uint32_t i = tid; i < p.scene.blob_vec4; i += BLOCK) lds[i] = p.scene.blob[i];
         __syncthreads();
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     const float4* mats16 = reinterpret_cast<const float4*>(scene_base + p.scene.off_mats);
     const float4* quads = reinterpret_cast<const float4*>(scene_base + p.scene.off_quads);
     // per-lane traversal stack of references (16 bits, BIG: 32).  Entry k of this lane is stack[k * 64].
-    ref_t* stack = reinterpret_cast<ref_t*>(lds + (BIG ? 0u : p.scene.blob_vec4)) + wave * 64u * p.scene.stack_cap + lane;
+    ref_t* stack = reinterpret_cast<ref_t*>(lds + (BIG ? p.scene.n_top * (RT_NODE_DWORDS_BIG / 4u) : p.scene.blob_vec4)) + wave * 64u * p.scene.stack_cap + lane;
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 uint32_t n_inner_lanes;
                 do {
                     if (at_inner) {
-                        const WideNodeData nd = fetch_wide_node<BIG>(nodes, cur, kx, ky, kz);
+                        const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
                         const uint32_t left_idx = nd.left, right_idx = nd.right;
                         float tl, tr;
                         const bool hl = slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     const bool at_irr = (cur & (K_LEAF | K_IRR)) == K_IRR;
                     if (__ballot(at_irr) == 0ull) break;
                     if (at_irr) {
-                        const WideNodeData nd = fetch_wide_node<BIG>(nodes, cur & (K_IRR - 1u), 0u, 0u, 0u);   // near = min, far = max
+                        const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur & (K_IRR - 1u), 0u, 0u, 0u);   // near = min, far = max
                         uint32_t left_idx = nd.left, right_idx = nd.right;
                         if (left_idx < K_LEAF) left_idx |= K_IRR;     // inner references stay marked all the way down
                         if (right_idx < K_LEAF) right_idx |= K_IRR;
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             while (m_inner != 0ull) {
                 if (at_inner) {
                     // kx/ky/kz are 0 in these kernels: near == box min, far == box max
-                    const WideNodeData nd = fetch_wide_node<BIG>(nodes, cur, 0u, 0u, 0u);
+                    const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, 0u, 0u, 0u);
                     const float lnx = nd.lnx, lny = nd.lny, lnz = nd.lnz, lfx = nd.lfx, lfy = nd.lfy, lfz = nd.lfz;
                     const float rnx = nd.rnx, rny = nd.rny, rnz = nd.rnz, rfx = nd.rfx, rfy = nd.rfy, rfz = nd.rfz;
                     const uint32_t left_idx = nd.left, right_idx = nd.right;
