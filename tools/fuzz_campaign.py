@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Differential fuzz campaign: random worlds (spheres, moving spheres, quads, lights, media, textures; every builder; LDS
+and global-memory paths; three cameras) rendered on the GPU and by the CPU oracle, compared bit for bit.
+    python tools/fuzz_campaign.py --seeds 200 [--first 0]
+Prints one line per failure and a summary; exit code 1 if anything differed."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as G
+import _oracle as O
+from _common import as_oracle_camera, as_oracle_world, bits_equal
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=100)
+ap.add_argument("--first", type=int, default=0)
+args = ap.parse_args()
+p = G.load_package()
+
+
+def image(h, w, rng):
+    return rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+
+
+def make_world(rng):
+    s = p.Scene()
+    kinds = rng.integers(0, 4)   # 0 spheres only (reference features), 1 + quads/lights/background, 2 + media, 3 + textures
+    mats = [s.Lambertian(rng.random(3)), s.Metal(rng.random(3), float(rng.choice([0.0, 0.1, 0.7, 1.0]))),
+            s.Dielectric((1, 1, 1), float(rng.choice([1.5, 1.33, 1 / 1.5, 2.4]))),
+            s.LambertianTexture(rng.random(3), rng.random(3), float(rng.choice([0.2, 0.5, 1.3])))]
+    if kinds >= 1:
+        mats.append(s.DiffuseLight(rng.random(3) * float(rng.choice([2.0, 8.0, 20.0]))))
+    if kinds >= 3:
+        s.set_perlin(int(rng.integers(0, 1 << 30)))
+        s.set_image(image(int(rng.integers(1, 40)), int(rng.integers(1, 60)), rng))
+        mats += [s.NoiseTexture(float(rng.choice([0.2, 1.0, 4.0])), rng.random(3)), s.ImageTexture()]
+    surf = list(mats)
+    media = []
+    if kinds >= 2:
+        media = [s.Isotropic(rng.random(3), float(rng.choice([0.01, 0.3, 2.0])))]
+    big = rng.random() < 0.15
+    n = int(rng.integers(1500, 2600)) if big else int(rng.integers(1, 70))
+    spread = 30.0 if big else 6.0
+    for i in range(n):
+        c = ((rng.random(3) * 2 - 1) * np.array([spread, 2, spread])).astype(np.float32)
+        r = float(rng.choice([0.05, 0.2, 0.6])) if big else float(rng.choice([0.05, 0.3, 0.8, 2.5]))
+        use_medium = media and rng.random() < 0.1
+        m = media[0] if use_medium else surf[int(rng.integers(0, len(surf)))]
+        if use_medium:
+            r *= 3
+        if rng.random() < 0.25:
+            s.MakeMovingSphere(c, c + (rng.random(3).astype(np.float32) - 0.5), r, m)
+        else:
+            s.MakeSphere(c, r, m)
+    if rng.random() < 0.5:
+        s.MakeSphere((0, -500.0, 0), 498.0, surf[int(rng.integers(0, 4))])
+    if kinds >= 1:
+        quad_mats = [m for m in surf if m != (mats[-1] if kinds >= 3 else -1)]   # no image texture on quads
+        for _ in range(int(rng.integers(1, 25))):
+            Q = ((rng.random(3) * 2 - 1) * np.array([spread, 3, spread])).astype(np.float32)
+            if rng.random() < 0.4:
+                u, v = np.float32([rng.random() * 4 + 0.3, 0, 0]), np.float32([0, 0, rng.random() * 4 + 0.3])
+            else:
+                u, v = (rng.standard_normal(3) * 2).astype(np.float32), (rng.standard_normal(3) * 2).astype(np.float32)
+            s.MakeQuad(Q, u, v, quad_mats[int(rng.integers(0, len(quad_mats)))])
+        if rng.random() < 0.3:
+            s.MakeBox((-1, 0, -1), (1.5, 2, 1), quad_mats[0], float(rng.uniform(-40, 40)), (rng.random(3) * 4).astype(np.float32))
+        if rng.random() < 0.6:
+            s.set_background(tuple(float(x) for x in rng.random(3) * 0.4))
+    builder = int(rng.integers(0, 4)) if not big else int(rng.integers(0, 2))
+    [s.BuildBVH_TopDown, s.BuildBVH_SAH, s.BuildBVH_BottomUp, s.MakeHittableList][builder]()
+    return s, kinds, builder, big
+
+
+fails = 0
+t0 = time.time()
+stats = {"lds": 0, "global": 0, "baseline": 0}
+for seed in range(args.first, args.first + args.seeds):
+    rng = np.random.default_rng(900000 + seed)
+    s, kinds, builder, big = make_world(rng)
+    W, H = int(rng.integers(17, 120)), int(rng.integers(9, 80))
+    spp, depth = int(rng.integers(1, 20)), int(rng.choice([1, 2, 5, 50]))
+    eye = ((rng.random(3) * 2 - 1) * np.array([9, 4, 9])).astype(np.float32)
+    if rng.random() < 0.1:
+        eye[int(rng.integers(0, 3))] = float(rng.choice([0.0, 1e-30, -1e-25]))   # rays outside the fast-division class
+    ck = int(rng.integers(0, 3))
+    if ck == 0:
+        cam = p.PinholeCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H)
+    elif ck == 1:
+        cam = p.DefocusBlurCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H, float(rng.uniform(0, 0.5)), float(rng.uniform(2, 12)))
+    else:
+        cam = p.MotionBlurCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H, 0.0, 1.0)
+    w = s.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    info = r.kernel_info()
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    r.close()
+    ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
+    stats["baseline" if info["variant"] == 1 else ("lds" if info["lds_resident"] else "global")] += 1
+    if info["variant"] == 1:
+        ok = np.array_equal(np.isnan(img), np.isnan(ref)) and float(np.nanmax(np.abs(img - ref))) <= 1e-5 * max(1.0, float(np.nanmax(ref)))
+    else:
+        ok = bits_equal(img, ref)
+    if not ok:
+        fails += 1
+        bad = int((img.view(np.uint32) != ref.view(np.uint32)).sum())
+        print(f"FAIL seed {seed}: kinds {kinds} builder {builder} big {big} cam {ck} {W}x{H}x{spp} depth {depth} info {info}: {bad} words differ", flush=True)
+    if (seed - args.first) % 25 == 24:
+        print(f"... {seed - args.first + 1} worlds, {fails} failures, {time.time() - t0:.0f}s, paths {stats}", flush=True)
+print(f"DONE: {args.seeds} worlds, {fails} failures, paths {stats}, {time.time() - t0:.0f}s")
+sys.exit(1 if fails else 0)
