@@ -15,6 +15,7 @@ from _common import as_oracle_camera, as_oracle_world, bits_equal
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=100)
 ap.add_argument("--first", type=int, default=0)
+ap.add_argument("--variants", action="store_true", help="pick a random kernel variant (0..4) per world; unsupported combinations are skipped")
 args = ap.parse_args()
 p = G.load_package()
 
@@ -92,7 +93,12 @@ for seed in range(args.first, args.first + args.seeds):
     else:
         cam = p.MotionBlurCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H, 0.0, 1.0)
     w = s.getWorldPtr()
-    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    variant = int(rng.integers(0, 5)) if args.variants else 0
+    try:
+        r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w, variant=variant)
+    except p.capi.RtError:
+        stats["refused"] = stats.get("refused", 0) + 1   # e.g. variant 4 on an extended world, variant 3 on a HittableList
+        continue
     info = r.kernel_info()
     r.Render()
     img = r.DownloadRenderbuffer()
