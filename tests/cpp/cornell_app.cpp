@@ -71,6 +71,38 @@ public:
     };
 };
 
+// A small world through the rest of the extension vocabulary: a constant medium (a Sphere of IsotropicAbstract), Perlin marble,
+// an image-textured sphere, a quad light — `cornell_app media` prints a hash that tests/test_cpp_api.py rebuilds in Python.
+using IsoSphere = IsotropicAbstract<Sphere>;
+using NoiseSphere = NoiseTextureAbstract<Sphere>;
+using ImageSphere = ImageTextureAbstract<Sphere>;
+using LambertianSphere = LambertianAbstract<Sphere>;
+struct MediaScene {
+    std::vector<SphereHandle> spheres;
+    std::vector<QuadHandle> quads;
+    std::unique_ptr<BVH_Handle> world;
+};
+static MediaScene* make_media_scene() {
+    auto* sc = new MediaScene();
+    std::vector<std::tuple<aabb, const Hittable*>> boxes;
+    auto add_sphere = [&](SphereHandle&& h) { sc->spheres.push_back(std::move(h)); boxes.push_back({sc->spheres.back().getBounds(), sc->spheres.back().getHittablePtr()}); };
+    add_sphere(SphereHandle::MakeSphere(Sphere(glm::vec3(0, -1000, 0), 1000.0f), newOnDevice<LambertianSphere>(glm::vec3(0.5f, 0.6f, 0.5f))));
+    add_sphere(SphereHandle::MakeSphere(Sphere(glm::vec3(0, 1, 0), 1.0f), newOnDevice<IsoSphere>(glm::vec3(0.2f, 0.4f, 0.9f), 0.5f)));
+    add_sphere(SphereHandle::MakeSphere(Sphere(glm::vec3(2.5f, 1, 0), 1.0f), newOnDevice<NoiseSphere>(4.0f)));
+    add_sphere(SphereHandle::MakeSphere(Sphere(glm::vec3(-2.5f, 1, 0), 1.0f), newOnDevice<ImageSphere>()));
+    sc->quads.push_back(QuadHandle::MakeQuad(Quad(glm::vec3(-1, 4, -1), glm::vec3(2, 0, 0), glm::vec3(0, 0, 2)), newOnDevice<LightQuad>(glm::vec3(8.0f))));
+    boxes.push_back({sc->quads.back().getBounds(), sc->quads.back().getHittablePtr()});
+    std::vector<uint8_t> img(8 * 4 * 3);
+    for (size_t i = 0; i < img.size(); i++) img[i] = (uint8_t)(i * 7u);
+    BVH_Handle::Factory f(boxes);
+    f.SetBackground(glm::vec3(0.1f, 0.1f, 0.2f));
+    f.SetPerlin(1984);
+    f.SetImage(8, 4, img.data());
+    f.BuildBVH_TopDown();
+    sc->world.reset(f.MakeHandle());
+    return sc;
+}
+
 static uint64_t fnv1a(const void* data, size_t n, uint64_t h = 1469598103934665603ull) {
     const unsigned char* p = static_cast<const unsigned char*>(data);
     for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -80,6 +112,32 @@ static uint64_t fnv1a(const void* data, size_t n, uint64_t h = 14695981039346656
 int main(int argc, char** argv) {
     try {
         std::string mode = argc > 1 ? argv[1] : "flatten";
+        if (mode == "media") {
+            MediaScene* sc = make_media_scene();
+            rt_world_flat w;
+            rt06::check(rt_scene_get_flat(sc->world->getBVHPtr()->scene, &w), "rt_scene_get_flat");
+            uint64_t h = fnv1a(w.nodes, sizeof(rt_bvh_node) * w.n_nodes);
+            for (uint32_t i = 0; i < w.n_prims; i++) {
+                rt_prim pr = w.prims[i];
+                rt_material m = w.materials[pr.mat & 0x7fffffffu];
+                pr.mat &= 0x80000000u;
+                h = fnv1a(&pr, sizeof(pr), h);
+                h = fnv1a(&m, sizeof(m), h);
+            }
+            for (uint32_t i = 0; i < w.n_quads; i++) {
+                rt_quad q = w.quads[i];
+                rt_material m = w.materials[q.mat];
+                q.mat = 0;
+                h = fnv1a(&q, sizeof(q), h);
+                h = fnv1a(&m, sizeof(m), h);
+            }
+            h = fnv1a(w.perlin, sizeof(rt_perlin), h);
+            h = fnv1a(w.image, (size_t)w.image_width * w.image_height * 3, h);
+            std::printf("media nodes=%u prims=%u quads=%u background=%u image=%ux%u fnv=%016llx\n", w.n_nodes, w.n_prims, w.n_quads, w.background,
+                        w.image_width, w.image_height, (unsigned long long)h);
+            delete sc;
+            return 0;
+        }
         SceneCornell::Factory scene_factory{};
         SceneCornell* scene_ptr = scene_factory.MakeScene();
         if (mode == "flatten") {

@@ -80,6 +80,41 @@ def test_cpp_quad_vocabulary_builds_the_cornell_box_prefab():
     assert int(m[7], 16) == fnv1a(chunks)
 
 
+def test_cpp_media_and_texture_vocabulary_flattens_like_the_python_one():
+    """IsotropicAbstract / NoiseTextureAbstract / ImageTextureAbstract / Factory::SetPerlin / SetImage / SetBackground (C++)
+    against Scene.Isotropic / NoiseTexture / ImageTexture / set_perlin / set_image / set_background (Python): same world."""
+    build_app()
+    out = subprocess.check_output([CORNELL, "media"], text=True)
+    m = re.search(r"nodes=(\d+) prims=(\d+) quads=(\d+) background=(\d+) image=(\d+)x(\d+) fnv=([0-9a-f]+)", out)
+    assert m, out
+    p = pkg()
+    s = p.Scene()
+    s.set_perlin(1984)
+    s.set_image((np.arange(8 * 4 * 3, dtype=np.uint32) * 7 % 256).astype(np.uint8).reshape(4, 8, 3))
+    s.MakeSphere((0, -1000, 0), 1000.0, s.Lambertian((0.5, 0.6, 0.5)))
+    s.MakeSphere((0, 1, 0), 1.0, s.Isotropic((0.2, 0.4, 0.9), 0.5))
+    s.MakeSphere((2.5, 1, 0), 1.0, s.NoiseTexture(4.0))
+    s.MakeSphere((-2.5, 1, 0), 1.0, s.ImageTexture())
+    s.MakeQuad((-1, 4, -1), (2, 0, 0), (0, 0, 2), s.DiffuseLight((8, 8, 8)))
+    s.set_background((0.1, 0.1, 0.2))
+    s.BuildBVH_TopDown()
+    nodes, prims, mats = s.arrays()
+    quads = s.quads()
+    w = s.getWorldPtr()
+    assert tuple(int(m[i]) for i in range(1, 7)) == (w.n_nodes, w.n_prims, w.n_quads, w.background, w.image_width, w.image_height)
+    chunks = [nodes.tobytes()]
+    for pr in prims:
+        p0 = pr.copy()
+        p0["mat"] = pr["mat"] & 0x80000000
+        chunks += [p0.tobytes(), mats[int(pr["mat"]) & 0x7fffffff].tobytes()]
+    for q in quads:
+        q0 = q.copy()
+        q0["mat"] = 0
+        chunks += [q0.tobytes(), mats[int(q["mat"])].tobytes()]
+    chunks += [s.perlin_bytes(), s.image().tobytes()]
+    assert int(m[7], 16) == fnv1a(chunks)
+
+
 @pytest.mark.gpu
 def test_cpp_cornell_render_matches_c_abi_path_bit_for_bit():
     build_app()
