@@ -73,18 +73,14 @@ RT_HD bool coord_is_regular(float b) {  // b == 0 or 2^-40 <= |b| < 2^40
 }
 
 __device__ __forceinline__ bool ray_is_regular(const Ray& ray) {
-    uint32_t ok = 1u;
-    const float dv[3] = {ray.d.x, ray.d.y, ray.d.z};
-    const float ov[3] = {ray.o.x, ray.o.y, ray.o.z};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        uint32_t ed = (__float_as_uint(dv[k]) >> 23) & 0xffu;   // 2^-40 <= |d| < 2^40
-        ok &= (ed >= 127u - 40u && ed <= 127u + 39u) ? 1u : 0u;
-        uint32_t uo = __float_as_uint(ov[k]);
-        uint32_t eo = (uo >> 23) & 0xffu;                        // o == 0 or 2^-60 <= |o| < 2^40
-        ok &= ((uo << 1) == 0u || (eo >= 127u - 60u && eo <= 127u + 39u)) ? 1u : 0u;
-    }
-    return ok != 0u;
+    // magnitudes as integers: for non-negative floats the bit patterns order like the values, inf / NaN are the largest
+    const uint32_t dx = __float_as_uint(ray.d.x) & 0x7fffffffu, dy = __float_as_uint(ray.d.y) & 0x7fffffffu, dz = __float_as_uint(ray.d.z) & 0x7fffffffu;
+    const uint32_t ox = __float_as_uint(ray.o.x) & 0x7fffffffu, oy = __float_as_uint(ray.o.y) & 0x7fffffffu, oz = __float_as_uint(ray.o.z) & 0x7fffffffu;
+    const uint32_t lo_d = (127u - 40u) << 23, hi = (127u + 40u) << 23, lo_o = (127u - 60u) << 23;   // 2^-40, 2^40, 2^-60
+    const uint32_t d_min = min(min(dx, dy), dz), d_max = max(max(dx, dy), dz);           // 2^-40 <= |d| < 2^40
+    // o == 0 or 2^-60 <= |o| < 2^40: subtracting one sends the pattern of zero to the top, so one minimum covers both cases
+    const uint32_t o_min = min(min(ox - 1u, oy - 1u), oz - 1u), o_max = max(max(ox, oy), oz);
+    return d_min >= lo_d && d_max < hi && o_min >= lo_o - 1u && o_max < hi;
 }
 
 // The box test of aabb.cuh:30-44 on a regular ray: same decisions, same dist (up to the sign of zero).
