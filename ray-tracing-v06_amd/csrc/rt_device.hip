@@ -405,6 +405,12 @@ struct rt_renderer {
             HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * 12ull)));
             if (pass_spp < cfg.samples_per_pixel) HIP_TRY(running.alloc((size_t)(n_local_pixels * 12ull)));
             HIP_TRY(hipFuncSetAttribute(stream_kernel_ptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
+            if (std::getenv("RT06_DEBUG")) {
+                int occ = -1;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, stream_kernel_ptr(), (int)stream_block, stream_lds_bytes);
+                fprintf(stderr, "[rt06] stream kernel: block %u, LDS %u B, planned %u blocks/CU, runtime occupancy query %d blocks/CU\n",
+                        stream_block, stream_lds_bytes, stream_blocks_per_cu, occ);
+            }
         }
         return RT_OK;
     }
