@@ -74,6 +74,8 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--verify-assembly", action="store_true",
+                    help="N > 1: after the timed region rank 0 renders the frame alone and requires the assembled image to be the same bits")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
     a.width = a.width or wl[4]
@@ -304,6 +306,16 @@ def main():
                 out["cpu_baseline"] = base
             if parity is not None:
                 out["parity"] = parity
+        if args.verify_assembly and world_size > 1:
+            solo = pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank, variant=args.variant)
+            solo.Render()
+            ref = solo.DownloadRenderbuffer()
+            solo.close()
+            got = image.cpu().numpy().reshape(H, W, 4)
+            same = got.tobytes() == ref.tobytes()
+            out["assembly_verified"] = bool(same)
+            if not same:
+                raise SystemExit("assembled multi-GPU image differs from the single-GPU image")
         print(json.dumps(out), flush=True)
     r.close()
     if world_size > 1:
