@@ -91,7 +91,7 @@ struct DeviceScene {
         const uint32_t sphere_codes = w->n_prims * 2u;
         if ((uint64_t)w->n_prims * 2u + w->n_quads >= (big ? 0x7ffffff0ull : (uint64_t)RT_REF_LEAF - 1u) || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // references would not fit
         if (big && w->kind != RT_WORLD_BVH) return RT_OK;
-        if (extended && w->kind != RT_WORLD_BVH) return RT_OK;  // quads / lights / background: the streaming kernel takes them in BVH worlds only
+        if (extended && w->kind == RT_WORLD_NODE_TREE) return RT_OK;  // quads / lights / background: BVH and HittableList worlds
         auto leaf_ref = [&](uint32_t prim) -> uint32_t {  // unified primitive index -> leaf reference
             if (prim >= w->n_prims) return ref_leaf | (sphere_codes + (prim - w->n_prims));
             return ref_leaf | (prim * 2u + ((w->prims[prim].mat & RT_PRIM_MOVING) ? 1u : 0u));
@@ -189,6 +189,7 @@ struct DeviceScene {
         packed.n_inner = n_inner;
         packed.n_codes = sphere_codes + w->n_quads;
         packed.n_prims = w->n_prims;
+        packed.n_quads = w->n_quads;
         packed.stack_cap = (true_stack ? true_stack : 1u) + 1u;  // + the sentinel entry at the bottom (RT_POP)
         packed.mats = mats.as<rt_material>();
         packed.perlin = dw.perlin; packed.image = dw.image; packed.image_w = dw.image_w; packed.image_h = dw.image_h;
@@ -423,6 +424,9 @@ struct rt_renderer {
             return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 1, true>)
                         : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 1, true>);
         }
+        if (scene.dw.kind == RT_WORLD_LIST && scene.extended)
+            return scene.textured ? reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST, 2>)
+                                  : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST, 1>);
         if (scene.extended) {
             if (scene.textured) return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 2>)
                                             : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 2>);

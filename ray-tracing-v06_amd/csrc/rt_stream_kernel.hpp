@@ -91,7 +91,7 @@ struct PackedSceneRef {
     uint32_t root_ref;
     float root_min[3], root_max[3];
     uint32_t stack_cap;      // entries per lane
-    uint32_t n_inner, n_codes, n_prims;
+    uint32_t n_inner, n_codes, n_prims, n_quads;
     uint32_t n_top;          // BIG: the first n_top wide nodes (breadth-first order = the top of the tree) are staged in the LDS
     const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
     const rt_perlin* perlin; // EXT: noise tables / image of the two textured materials (global memory), or null
@@ -448,19 +448,25 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             uint64_t m_leaf = __ballot(at_leaf);
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < K_LEAF) == 0ull)) {
                 if (at_leaf) {
-                    uint32_t code = cur & (K_LEAF - 1u);   // BVH / tree: prim * 2 + is_moving;  list: prim
-                    if (EXT && code >= p.scene.sphere_codes) {
+                    uint32_t code = cur & (K_LEAF - 1u);   // BVH / tree: prim * 2 + is_moving;  list: unified primitive index
+                    const uint32_t first_quad = (WORLD == RT_WORLD_LIST) ? p.scene.n_prims : p.scene.sphere_codes;
+                    if (EXT && code >= first_quad) {
                         // quad::hit ("The Next Week"), reference conventions: see quad_closest_intersection()
-                        const float4* qd = quads + (code - p.scene.sphere_codes) * 5u;
+                        const float4* qd = quads + (code - first_quad) * 5u;
                         float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a3 = qd[3], a4 = qd[4];
                         HitRec tmp;
                         tmp.distance = rec_t; tmp.normal = mk3(0.0f); tmp.prim = -1; tmp.mat = 0;
                         if (quad_closest_intersection(mk3(a0.x, a0.y, a0.z), a0.w, mk3(a1.x, a1.y, a1.z), mk3(a2.x, a2.y, a2.z),
                                                       mk3(a3.x, a3.y, a3.z), mk3(a4.x, a4.y, a4.z), 0u, 0, ray, tmp)) {
                             rec_t = tmp.distance;
-                            rec_code = (int32_t)code;
+                            rec_code = (int32_t)(code - first_quad + p.scene.sphere_codes);   // the shade phase's code space
                         }
-                        RT_POP();
+                        if (WORLD == RT_WORLD_LIST) {  // HittableList.cuh:26-30: every object, in order (the quads follow the spheres)
+                            if (code + 1u < p.scene.n_prims + p.scene.n_quads) cur = K_LEAF | (code + 1u);
+                            else cur = K_SHADE;
+                        } else {
+                            RT_POP();
+                        }
                     } else {
                     uint32_t prim = (WORLD == RT_WORLD_LIST) ? code : code >> 1;
                     float4 sph = spheres[prim];
@@ -471,6 +477,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         const uint32_t moving = (__float_as_uint(ex.w) >> 28) & 1u;
                         code = prim * 2u + moving;
                         if (moving) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
+                        sph_matbits = __float_as_uint(ex.w);
                     } else if (EXT || (code & 1u)) {
                         float4 ex = extra[prim];
                         if (code & 1u) center = mix(center, mk3(ex.x, ex.y, ex.z), ray.time);
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         rec_code = (int32_t)code;
                     }
                     if (WORLD == RT_WORLD_LIST) {  // HittableList.cuh:26-30: every object, in order
-                        if (prim + 1u < p.scene.n_prims) cur = K_LEAF | (prim + 1u);
+                        if (prim + 1u < p.scene.n_prims + (EXT ? p.scene.n_quads : 0u)) cur = K_LEAF | (prim + 1u);
                         else cur = K_SHADE;
                     } else {
                         RT_POP();
