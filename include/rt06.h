@@ -257,8 +257,11 @@ typedef struct rt_render_config {
     /* tile sharding across the GPUs of one node: this renderer owns the 8x8
      * pixel tiles t with t % world_size == rank (row-major tile order).      */
     uint32_t rank, world_size;
-    uint32_t variant;             /* 0 = default; 1 baseline, 2 LDS streaming (verbatim box tests), 3 = 2 + fast exact
-                                     division, 4 = 3 + filtered predicates (experimental).  Same image bits for all >= 2. */
+    uint32_t variant;             /* 0 = default (3 where the world allows it, else 2, else 1); 1 baseline wave-per-pixel kernel,
+                                     2 streaming kernel with verbatim box tests (IEEE divisions), 3 = 2 + exact division without
+                                     dividing (BVH worlds with box coordinates in [2^-40, 2^40)), 4 = 3 + filtered predicates
+                                     (experimental, reference features only).  Same image bits for all >= 2; worlds beyond the
+                                     LDS take the global-memory form of 2 / 3 (rt_renderer_kernel_info).                       */
 } rt_render_config;
 
 /* Renderer::MakeRenderer (Renderer.cu:31-67).  Copies the flat world and the
