@@ -354,7 +354,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #ifdef RT_PHASE_TIMERS
                     pc_[6]++;
 #endif
-                } while (n_inner_lanes >= p.inner_keep);   // inner_keep >= 1 (host)
+                } while (n_inner_lanes >= (pool_dry ? 1u : p.inner_keep));   // inner_keep >= 1 (host); once the queue is dry the wave
+                                                                              // only drains its last paths: no reason to leave early
             }
             RT_PT(0);
             if (irr_pending) {   // wave-uniform, rare: rays with a zero / tiny / huge direction or origin component

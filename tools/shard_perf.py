@@ -4,7 +4,7 @@ import __graft_entry__ as G
 p = G.load_package()
 W,H,spp=1200,800,500
 scene=p.Scene.book1_final(1984); cam=p.DefocusBlurCamera((13,2,3),(0,0,0),(0,1,0),20.0,W/H,0.1,10.0)
-for ws in (1,8):
+for ws in (1,2,4,8,16):
     r=p.Renderer.MakeRenderer(W,H,spp,50,cam,scene.getWorldPtr(),rank=0,world_size=ws)
     best=1e9
     for i in range(4):
