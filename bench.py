@@ -74,6 +74,11 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
+                    help="frames in flight: 2 renders frame k+1 on a second HIP stream while frame k drains its last paths and is gathered "
+                         "(two renderers, two shard buffers; the collectives stay on one stream, in order); 1 = strictly serial; "
+                         "0 (default) = 1.  Measured: no gain on one GPU (a persistent workgroup frees its LDS only when its last wave "
+                         "ends, so the next frame cannot move in early); on several GPUs it hides the gather behind the next render")
     ap.add_argument("--verify-assembly", action="store_true",
                     help="N > 1: after the timed region rank 0 renders the frame alone and requires the assembled image to be the same bits")
     a = ap.parse_args()
@@ -212,32 +217,46 @@ def main():
     W, H, spp = args.width, args.height, args.spp
     scene, cam = make_workload(args, pkg)
     world = scene.getWorldPtr()
-    r = pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank,
-                                  rank=rank, world_size=world_size, variant=args.variant)
+    # `depth` frames in flight: renderer / buffers / side stream d serve the frames k with k % depth == d
+    depth = args.pipeline if args.pipeline else 1
+    rs = [pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank,
+                                    rank=rank, world_size=world_size, variant=args.variant) for _ in range(depth)]
+    r = rs[0]
     stream = torch.cuda.current_stream()
-    image = torch.zeros(H * W * 4, dtype=torch.float32, device=dev) if rank == 0 else None
+    side = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [stream]
+    images = [torch.zeros(H * W * 4, dtype=torch.float32, device=dev) if rank == 0 else None for _ in range(depth)]
+    image = images[0]
     from ray_tracing_v06_amd import multigpu
-    if world_size > 1:
-        shard = torch.zeros(r.shard_floats(), dtype=torch.float32, device=dev)
+    shards = [torch.zeros(r.shard_floats(), dtype=torch.float32, device=dev) for _ in range(depth)] if world_size > 1 else None
+    rendered = [torch.cuda.Event() for _ in range(depth)]
+    consumed = [torch.cuda.Event() for _ in range(depth)]
+    for e in consumed:
+        e.record(stream)
 
     kernel_events = []
+    frame = [0]
 
     def step(record):
+        d = frame[0] % depth
+        frame[0] += 1
+        sd = side[d]
+        sd.wait_event(consumed[d])            # the buffers of this slot are free again (frame k - depth was gathered / assembled)
         e0 = e1 = None
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        if world_size == 1:
-            r.render_async(stream.cuda_stream, image.data_ptr())
-        else:
-            r.render_async(stream.cuda_stream, shard.data_ptr())
+            e0.record(sd)
+        target = images[d] if world_size == 1 else shards[d]
+        rs[d].render_async(sd.cuda_stream, target.data_ptr())
         if record:
-            e1.record(stream)
+            e1.record(sd)
             kernel_events.append((e0, e1))
+        rendered[d].record(sd)
+        stream.wait_event(rendered[d])        # everything after the render stays on ONE stream, in frame order
         if world_size > 1:
-            gathered = multigpu.gather_shards(shard, world_size, rank, dst=0)  # the single frame-end exchange (RCCL over xGMI)
+            gathered = multigpu.gather_shards(shards[d], world_size, rank, dst=0)  # the single frame-end exchange (RCCL over xGMI)
             if rank == 0:
-                r.assemble(gathered.data_ptr(), image.data_ptr(), stream.cuda_stream)
+                rs[d].assemble(gathered.data_ptr(), images[d].data_ptr(), stream.cuda_stream)
+        consumed[d].record(stream)
 
     def fence():
         if world_size > 1:
@@ -257,6 +276,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_events])) if kernel_events else float("nan")
+    kernel_ms_source = "HIP events around every launch of the timed region"
+    if depth > 1:
+        # frames overlap inside the timed region, so an event pair there spans the wait for the previous frame's workgroups too:
+        # take the kernel's duration from ONE more launch on the drained GPU (untimed, after the timed region)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        rs[0].render_async(stream.cuda_stream, (images[0] if world_size == 1 else shards[0]).data_ptr())
+        e1.record(stream)
+        torch.cuda.synchronize()
+        kernel_ms = float(e0.elapsed_time(e1))
+        kernel_ms_source = "one serial launch after the timed region (two frames are in flight inside it)"
+        if world_size > 1:
+            dist.barrier()
 
     total_samples = float(W) * H * spp
     out = None
@@ -280,8 +312,9 @@ def main():
             "config": {"workload": f"{WORKLOADS[args.workload][8]}, {W}x{H}, {spp} spp, "
                                    f"max_depth {args.depth}, seed {args.seed}, {WORKLOADS[args.workload][9]}",
                        "parallelism": f"tile-shard x{world_size} + 1 RCCL gather" if world_size > 1 else "single GPU",
+                       "frames_in_flight": depth,
                        "kernel_variant": args.variant},
-            "kernel_ms_per_step_rank0": round(kernel_ms, 3),
+            "kernel_ms_per_step_rank0": round(kernel_ms, 3), "kernel_ms_source": kernel_ms_source,
         }
         if counts is None:
             counts = count_leg(args)
@@ -311,13 +344,14 @@ def main():
             solo.Render()
             ref = solo.DownloadRenderbuffer()
             solo.close()
-            got = image.cpu().numpy().reshape(H, W, 4)
+            got = images[(frame[0] - 1) % depth].cpu().numpy().reshape(H, W, 4)   # the last frame rendered
             same = got.tobytes() == ref.tobytes()
             out["assembly_verified"] = bool(same)
             if not same:
                 raise SystemExit("assembled multi-GPU image differs from the single-GPU image")
         print(json.dumps(out), flush=True)
-    r.close()
+    for rr in rs:
+        rr.close()
     if world_size > 1:
         dist.destroy_process_group()
 
