@@ -249,3 +249,22 @@ def test_book2_final_prefab_matches_oracle_bit_for_bit():
     oimg = bytes((C.c_char * (256 * 128 * 3)).from_address(ow.image))
     assert img.shape == (128, 256, 3) and img.tobytes() == oimg
     assert sorted(int(t) for t in mats["type"]) == [0, 0, 0, 1, 2, 4, 5, 5, 6, 7]
+
+
+def test_bench_workload_table_builds_matching_product_and_oracle_scenes():
+    """bench.py --workload: every entry must construct the same world through the product host code and the oracle."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    p = pkg()
+    assert set(bench.WORKLOADS) == {"book1_final", "book2_moving", "cornell_box", "book2_final"}
+    for name, wl in bench.WORKLOADS.items():
+        args = argparse.Namespace(workload=name, width=wl[4], height=wl[5], spp=wl[6], depth=wl[7], seed=1984)
+        scene, cam = bench.make_workload(args, p)
+        oscene, ocam = bench.make_workload(args, O, oracle=True)
+        w, ow = scene.getWorldPtr(), oscene.world
+        assert (w.kind, w.n_nodes, w.n_prims, w.n_quads, w.n_materials) == (ow.kind, ow.n_nodes, ow.n_prims, ow.n_quads, ow.n_materials), name
+        assert scene.arrays()[0].tobytes() == oscene.nodes.tobytes(), name
+        assert bytes(cam) == bytes(ocam), name
