@@ -11,7 +11,8 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(CSRC_DIR, "librt06.so")
+# RT06_LIB: development only — another build of the SAME library (e.g. one compiled with -DRT_PHASE_TIMERS); never a fallback
+LIB_PATH = os.environ.get("RT06_LIB") or os.path.join(CSRC_DIR, "librt06.so")
 
 RT_OK = 0
 RT_PRIM_MOVING = 0x80000000

@@ -191,6 +191,9 @@ struct DeviceScene {
         packed.n_prims = w->n_prims;
         packed.n_quads = w->n_quads;
         packed.stack_cap = (true_stack ? true_stack : 1u) + 1u;  // + the sentinel entry at the bottom (RT_POP)
+#ifdef RT_BRANCHLESS_STACK
+        packed.stack_cap += 1u;  // the unconditional far-child store may touch one entry above the deepest push
+#endif
         packed.mats = mats.as<rt_material>();
         packed.perlin = dw.perlin; packed.image = dw.image; packed.image_w = dw.image_w; packed.image_h = dw.image_h;
         has_packed = true;
@@ -323,6 +326,10 @@ struct rt_renderer {
     DevBuf fb;
     DevBuf work_counter;
     DevBuf samples, running;     // sample buffer of one pass; running sums when spp needs several passes
+    // primary rays of one pass: 3 arrays of 16 B per sample index (origin|time, direction, RNG state).  Generated on the render's
+    // own stream, before the streaming kernel: generating pass k + 1 on a second stream WHILE pass k is traced was measured and is
+    // harmful (the persistent kernel ran 40 % slower with the generator's waves co-resident: 100 ms instead of 70).
+    DevBuf primary[1];
     uint32_t pass_spp = 0;       // samples per pixel per pass
     uint32_t n_cus = 0;
     uint32_t stream_lds_bytes = 0;
@@ -394,7 +401,7 @@ struct rt_renderer {
             }
         }
         if (variant >= 2) {
-            uint64_t budget = 8ull << 30;  // HBM for one pass of per-sample radiance (12 B each)
+            uint64_t budget = 8ull << 30;  // HBM for one pass of per-sample radiance (12 B each; the primary-ray records add 48 B each)
             if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // tests force multi-pass rendering with this
                 unsigned long long v = std::strtoull(env, nullptr, 10);
                 if (v >= 12) budget = v;
@@ -404,6 +411,7 @@ struct rt_renderer {
             pass_spp = (uint32_t)std::min<uint64_t>(cfg.samples_per_pixel, max_spp);
             if (n_local_pixels * pass_spp >= 0xF0000000ull) return rt_fail(RT_ERR_INVALID, "image too large for one pass");
             HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * 12ull)));
+            HIP_TRY(primary[0].alloc((size_t)(n_local_pixels * pass_spp * 48ull)));
             if (pass_spp < cfg.samples_per_pixel) HIP_TRY(running.alloc((size_t)(n_local_pixels * 12ull)));
             HIP_TRY(hipFuncSetAttribute(stream_kernel_ptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
             if (std::getenv("RT06_DEBUG")) {
@@ -481,17 +489,36 @@ struct rt_renderer {
             HIP_TRY(hipMemsetAsync(work_counter.p, 0, 4, st));
 #ifdef RT_PHASE_TIMERS
             DevBuf phase_acc;
-            HIP_TRY(phase_acc.alloc(32 * sizeof(unsigned long long)));
-            HIP_TRY(hipMemsetAsync(phase_acc.p, 0, 32 * sizeof(unsigned long long), st));
+            HIP_TRY(phase_acc.alloc((32 + 96 * 16) * sizeof(unsigned long long)));
+            HIP_TRY(hipMemsetAsync(phase_acc.p, 0, (32 + 96 * 16) * sizeof(unsigned long long), st));
             p.phase_acc = phase_acc.as<unsigned long long>();
 #endif
+            const int pb = 0;
+            {
+                const size_t n_pass = (size_t)tm.n_local_tiles * RT_TILE * RT_TILE * pass_spp;   // 16-B records per array
+                p.prim_o = primary[pb].as<float4>();
+                p.prim_d = primary[pb].as<float4>() + n_pass;
+                p.prim_rng = reinterpret_cast<uint4*>(primary[pb].as<float4>() + 2 * n_pass);
+            }
+            for (uint32_t b0 = 0; b0 < tm.n_local_tiles; b0 += 65535u) {   // grid.y = 64-pixel block, at most 65535 per launch
+                const uint32_t nb = std::min(65535u, tm.n_local_tiles - b0);
+                primary_rays_kernel<<<dim3((64u * p.pass_spp + 255u) / 256u, nb), 256, 0, st>>>(p, b0);
+                HIP_TRY(hipGetLastError());
+            }
+
             void* args[] = {&p};
             HIP_TRY(hipLaunchKernel(stream_kernel_ptr(), dim3(grid), dim3(stream_block), args, stream_lds_bytes, st));
 #ifdef RT_PHASE_TIMERS
             {
-                unsigned long long h[32];
+                static unsigned long long h[32 + 96 * 16];
                 HIP_TRY(hipStreamSynchronize(st));
                 HIP_TRY(hipMemcpy(h, phase_acc.p, sizeof(h), hipMemcpyDeviceToHost));
+                if (const char* hp = std::getenv("RT06_TRACE_HIST")) {   // joint histogram (inner steps x leaf tests) per trace, for tools/sched_model.py
+                    if (FILE* f = std::fopen(hp, "w")) {
+                        for (int a = 0; a < 96; a++) { for (int b = 0; b < 16; b++) std::fprintf(f, "%llu ", h[32 + a * 16 + b]); std::fprintf(f, "\n"); }
+                        std::fclose(f);
+                    }
+                }
                 static const char* names[16] = {"hot inner loop", "irregular loop", "leaf phase", "shade (tail)", "regenerate", "begin trace", "(inner steps)", "loop top",
                                                 "schedule check", "shade: miss/sky + hit common", "shade: dielectric prep", "shade: dielectric dir", "shade: on-unit-sphere loop", "shade: metal/lambert/checker", "-", "-"};
                 unsigned long long tot = 0;

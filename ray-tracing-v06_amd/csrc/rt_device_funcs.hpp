@@ -338,15 +338,20 @@ RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRe
     return true;
 }
 
-// sample_ray — PinholeCamera (cu_Cameras.cuh:27-30), DefocusBlurCamera (:54-64), MotionBlurCamera (:87-89)
-RT_HD Ray camera_sample_ray(const rt_camera& c, float s, float t, Rng& rng) {
+// sample_ray — PinholeCamera (cu_Cameras.cuh:27-30), DefocusBlurCamera (:54-64), MotionBlurCamera (:87-89), in two halves:
+// camera_draw consumes the camera's uniforms (defocus: the lens point InUnit<2>; motion: one uniform -> time), camera_ray
+// is the arithmetic.  The streaming path runs the first half in primary_rays_kernel and the second at regeneration.
+RT_HD void camera_draw(const rt_camera& c, Rng& rng, float& a, float& b) {
+    a = 0.0f; b = 0.0f;
+    if (c.type == RT_CAM_DEFOCUS) rng_in_unit2(rng, a, b);                // a, b = lens point in the unit disc
+    else if (c.type == RT_CAM_MOTION) a = mix(c.t0, c.t1, rng.next());  // a = ray time
+}
+RT_HD Ray camera_ray(const rt_camera& c, float s, float t, float a, float b) {
     Ray r;
     f3 o = mk3(c.o[0], c.o[1], c.o[2]), u = mk3(c.u[0], c.u[1], c.u[2]);
     f3 v = mk3(c.v[0], c.v[1], c.v[2]), w = mk3(c.w[0], c.w[1], c.w[2]);
     if (c.type == RT_CAM_DEFOCUS) {
-        float dx, dy;
-        rng_in_unit2(rng, dx, dy);
-        f3 offset = u * dx + v * dy;
+        f3 offset = u * a + v * b;
         offset = offset * c.lens_radius;
         f3 forward = w * c.focus_dist;
         f3 hori = u * c.viewport_width * c.focus_dist;
@@ -357,9 +362,14 @@ RT_HD Ray camera_sample_ray(const rt_camera& c, float s, float t, Rng& rng) {
     } else {
         r.o = o;
         r.d = w + u * s + v * t;
-        r.time = (c.type == RT_CAM_MOTION) ? mix(c.t0, c.t1, rng.next()) : 0.0f;
+        r.time = a;   // 0 for a pinhole camera
     }
     return r;
+}
+RT_HD Ray camera_sample_ray(const rt_camera& c, float s, float t, Rng& rng) {
+    float a, b;
+    camera_draw(c, rng, a, b);
+    return camera_ray(c, s, t, a, b);
 }
 
 // sample_world, main/src/Renderer.cu:139-181.  The emission / background hooks are the reference's own commented

@@ -111,6 +111,10 @@ struct StreamParams {
     uint32_t inner_keep, shade_min, leaf_min;
     uint32_t chunk;          // sample indices per work-queue fetch
     float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
+    // primary rays of the pass, written by primary_rays_kernel and consumed by sample regeneration, indexed by n:
+    float4* prim_o;          // (ray origin, ray time)
+    float4* prim_d;          // (ray direction, -)
+    uint4* prim_rng;         // the sample's RNG state after the camera's draws; all zero (never a valid state) marks a padding pixel
     uint32_t* work_counter;
 #ifdef RT_PHASE_TIMERS
     unsigned long long* phase_acc;  // development build only: [0..15] cycles per phase, [16..31] visits (summed over waves)
@@ -240,7 +244,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
-    const uint32_t spb = 64u * p.pass_spp;  // sample indices per 64-pixel block
 
     // ---- per-lane path state ------------------------------------------------------------------------
     Ray ray;
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     f3 atten = mk3(0.0f);
     f3 accum_rad = mk3(0.0f);  // EXT only: radiance emitted along the path so far
     Rng rng;
-    rng.init(p.seed, 0u, 0u, RT_STREAM_RENDER);
+    rng.s0 = 1u; rng.s1 = 0u; rng.s2 = 0u; rng.s3 = 0u; rng.draws = 0u;   // every sample brings its own state (primary_rays_kernel)
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
     uint32_t cur = K_NEED;   // node reference being visited, or the lane's status (see RT_CUR_*)
@@ -265,11 +268,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     uint32_t depth = 0;
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
 
-    // ---- wave-uniform work pool: [pool_next, pool_end) + the tile origins of its current block(s) -----
+    // ---- wave-uniform work pool: sample indices [pool_next, pool_end) ----------------------------------
     uint32_t pool_next = 0, pool_end = 0;
-    uint32_t pool_blk = 0, pool_rem = 0;      // pool_next == pool_blk * spb + pool_rem
-    uint32_t ax0 = 0, ay0 = 0, bx0 = 0, by0 = 0;
-    bool a_ok = false, b_ok = false;          // origin/validity of block pool_blk (a) and pool_blk + 1 (b)
     bool pool_dry = false;
 
 // BVH.cu:59-60 / HittableList.cuh:22: root (world) box first, against rec.distance (= _MISS_DIST for a fresh
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #ifdef RT_PHASE_TIMERS
     unsigned long long pt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last_ = __builtin_readcyclecounter();
     uint32_t pc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t tr_steps_ = 0, tr_leafs_ = 0;   // per lane: inner-node steps / leaf tests of the current trace (histogram for tools/sched_model.py)
 #define RT_PT(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pt_last_; pt_last_ = n_; pc_[i]++; } while (0)
 #else
 #define RT_PT(i)
@@ -333,6 +334,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 uint32_t n_inner_lanes;
                 do {
                     if (at_inner) {
+#ifdef RT_BRANCHLESS_STACK
+                        const ref_t top_ = *(sp - 64);
+#endif
                         const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
                         const uint32_t left_idx = nd.left, right_idx = nd.right;
                         float tl, tr;
@@ -342,12 +346,26 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".
                         const bool go_right = hr && (!hl || tl > tr);
+#ifdef RT_BRANCHLESS_STACK
+                        // experiment: no exec-mask manipulation for push / pop (scalar instructions are not free on gfx950):
+                        // the far child is written unconditionally into the free slot (harmless unless both boxes are hit)
+                        // and the entry below the top was read speculatively together with the node
+                        *sp = (ref_t)(go_right ? left_idx : right_idx);
+                        const bool both = hl && hr, none = !(hl || hr);
+                        cur = none ? (uint32_t)top_ : (go_right ? right_idx : left_idx);
+                        sp += both ? 64 : 0;
+                        sp -= none ? 64 : 0;
+#else
                         if (hl && hr) {
                             *sp = (ref_t)(go_right ? left_idx : right_idx);
                             sp += 64;
                         }
                         cur = go_right ? right_idx : left_idx;
                         if (!(hl || hr)) RT_POP();
+#endif
+#ifdef RT_PHASE_TIMERS
+                        tr_steps_++;
+#endif
                     }
                     at_inner = cur < K_IRR;
                     n_inner_lanes = (uint32_t)__popcll(__ballot(at_inner));
@@ -449,6 +467,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             uint64_t m_leaf = __ballot(at_leaf);
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < K_LEAF) == 0ull)) {
                 if (at_leaf) {
+#ifdef RT_PHASE_TIMERS
+                    tr_leafs_++;
+#endif
                     uint32_t code = cur & (K_LEAF - 1u);   // BVH / tree: prim * 2 + is_moving;  list: unified primitive index
                     const uint32_t first_quad = (WORLD == RT_WORLD_LIST) ? p.scene.n_prims : p.scene.sphere_codes;
                     if (EXT && code >= first_quad) {
@@ -514,6 +535,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
         RT_PT(8);
         if (cur == K_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
+#ifdef RT_PHASE_TIMERS
+            atomicAdd(p.phase_acc + 32 + min(tr_steps_, 95u) * 16u + min(tr_leafs_, 15u), 1ull);
+            tr_steps_ = 0; tr_leafs_ = 0;
+#endif
             if (rec_code < 0) {
                 f3 sky;
                 if (EXT && p.scene.background == 1u) {
@@ -619,7 +644,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         }
 
         RT_PT(3);
-        // ---- hand new samples to the lanes that need one (wave-uniform loop) -------------------------
+        // ---- hand new samples to the lanes that need one (wave-uniform loop).  The primary ray of sample index n
+        // ---- (pixel jitter, camera sample, RNG state after those draws: Renderer.cu:199-201) was computed by
+        // ---- primary_rays_kernel with every lane busy; here a lane only loads its 48-byte record.
         for (;;) {
             uint64_t m_need = __ballot(cur == K_NEED);
             if (m_need == 0ull) break;
@@ -631,30 +658,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 if (base >= p.total) { pool_dry = true; break; }
                 pool_next = base;
                 pool_end = min(base + p.chunk, p.total);
-                pool_blk = base / spb;
-                pool_rem = base - pool_blk * spb;
-                a_ok = block_origin(p.tm, pool_blk, ax0, ay0);
-                b_ok = block_origin(p.tm, pool_blk + 1u, bx0, by0);
             }
             uint32_t take = min(pool_end - pool_next, (uint32_t)__popcll(m_need));
             uint32_t rank = lane_rank(m_need);
             if (cur == K_NEED && rank < take) {
-                // sample index n -> (64-pixel block, sample, pixel in block): n = (blk * pass_spp + s) * 64 + pix
-                uint32_t rem = pool_rem + rank;
-                bool second = rem >= spb;  // rank < 64 <= spb: at most one block boundary
-                if (second) rem -= spb;
-                uint32_t s_local = rem >> 6, pix = rem & 63u;
-                uint32_t x = (second ? bx0 : ax0) + (pix & 7u);
-                uint32_t y = (second ? by0 : ay0) + (pix >> 3);
-                if ((second ? b_ok : a_ok) && x < p.width && y < p.height) {
-                    uint32_t gid = y * p.width + x;
-                    out_idx = pool_next + rank;
-                    rng.init(p.seed, gid, p.pass_first_s + s_local, RT_STREAM_RENDER);
-                    float psx, psy, ndcx, ndcy;
-                    pixel_ndc(x, y, p.width, p.height, psx, psy, ndcx, ndcy);
-                    float jx, jy;
-                    rng_in_unit2(rng, jx, jy);  // Renderer.cu:199
-                    ray = camera_sample_ray(p.cam, ndcx + jx * psx, ndcy + jy * psy, rng);
+                const uint32_t n = pool_next + rank;
+                const uint4 rs = p.prim_rng[n];
+                if ((rs.x | rs.y | rs.z | rs.w) != 0u) {
+                    const float4 po = p.prim_o[n], pd = p.prim_d[n];
+                    out_idx = n;
+                    ray.o = mk3(po.x, po.y, po.z); ray.d = mk3(pd.x, pd.y, pd.z); ray.time = po.w;
+                    rng.s0 = rs.x; rng.s1 = rs.y; rng.s2 = rs.z; rng.s3 = rs.w;
                     atten = mk3(1.0f);
                     if (EXT) accum_rad = mk3(0.0f);
                     depth = 0;
@@ -668,13 +682,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again
             }
             pool_next += take;
-            pool_rem += take;
-            if (pool_rem >= spb) {
-                pool_rem -= spb;
-                pool_blk++;
-                ax0 = bx0; ay0 = by0; a_ok = b_ok;
-                b_ok = block_origin(p.tm, pool_blk + 1u, bx0, by0);
-            }
         }
         RT_PT(4);
         if (start_trace) RT_BEGIN_TRACE();
@@ -692,6 +699,53 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #undef RT_POP
 #undef RT_EMIT
 #undef RT_EMIT_DARK
+}
+
+// Primary rays of one pass: one thread per sample index n = (block * pass_spp + s) * 64 + pixel-in-block (the index space
+// the streaming kernel consumes; blockIdx.y = block, so no integer division).  Renderer.cu:188-201: pixel centre in NDC,
+// jitter in a disc of half a pixel (cuRandomInUnit<2>), camera sample_ray — with the per-sample counter-based RNG stream
+// (Philox seed, then the sequential draws).  Done here, with every lane busy, instead of inside the persistent kernel where
+// only the ~21 lanes of a wave whose path just ended would run it (it was 12 % of that kernel's time at one-third lane
+// utilisation).  Writes 48 B per sample: (origin, time), (direction, -), RNG state after the camera's draws.
+// The two rejection loops of a defocus camera (pixel jitter, lens point: glm_utils.h:84-90 twice) run as ONE loop whose
+// iterations serve whichever of the two a lane is at — the same draws in the same order per lane, but the wave iterates
+// max(tries_jitter + tries_lens) times instead of max(tries_jitter) + max(tries_lens).
+__global__ __launch_bounds__(256) void primary_rays_kernel(StreamParams p, uint32_t first_blk) {
+    const uint32_t blk = first_blk + blockIdx.y;
+    const uint32_t rem = blockIdx.x * 256u + threadIdx.x;   // index inside the block's 64 * pass_spp samples
+    if (rem >= 64u * p.pass_spp) return;
+    const uint32_t n = blk * (64u * p.pass_spp) + rem;
+    const uint32_t s_local = rem >> 6, pix = rem & 63u;
+    uint32_t x0, y0;
+    const bool ok = block_origin(p.tm, blk, x0, y0);
+    const uint32_t x = x0 + (pix & 7u), y = y0 + (pix >> 3);
+    if (!(ok && x < p.width && y < p.height)) {   // padding pixel: outside the image / past the last tile
+        p.prim_rng[n] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    Rng rng;
+    rng.init(p.seed, y * p.width + x, p.pass_first_s + s_local, RT_STREAM_RENDER);
+    float psx, psy, ndcx, ndcy;
+    pixel_ndc(x, y, p.width, p.height, psx, psy, ndcx, ndcy);
+    float jx = 0.0f, jy = 0.0f, a = 0.0f, b = 0.0f;
+    if (p.cam.type == RT_CAM_DEFOCUS) {
+        uint32_t stage = 0;   // 0: pixel jitter (Renderer.cu:199), 1: lens point (cu_Cameras.cuh:55), 2: done
+        do {
+            const float u = rng.next() * 2.0f - 1.0f;
+            const float v = rng.next() * 2.0f - 1.0f;
+            if (length2(u, v) < 1.0f) {
+                if (stage == 0u) { jx = u; jy = v; } else { a = u; b = v; }
+                stage++;
+            }
+        } while (stage < 2u);
+    } else {
+        rng_in_unit2(rng, jx, jy);
+        camera_draw(p.cam, rng, a, b);
+    }
+    const Ray ray = camera_ray(p.cam, ndcx + jx * psx, ndcy + jy * psy, a, b);
+    p.prim_o[n] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.time);
+    p.prim_d[n] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+    p.prim_rng[n] = make_uint4(rng.s0, rng.s1, rng.s2, rng.s3);
 }
 
 // Adds the samples of one pass to each pixel IN SAMPLE ORDER (Renderer.cu:198-204: `radiance += ...`),
