@@ -335,6 +335,16 @@ int rt_probe_rng(int device, uint64_t seed, size_t n, const uint32_t* keys, uint
  * argument, ignored otherwise): out[i] = f(a[i], b[i])                                                        */
 int rt_probe_math(int device, int fn, size_t n, const float* a, const float* b, float* out);
 
+/* The device math vocabulary (csrc/rt_math.hpp: GLM's dot / cross / normalize / reflect / refract / mix / min / max /
+ * compMax / compMin / clamp+sqrt / radians and glm_utils.h's near_zero / length2 / linear_interpolate; fn = 0..15 in the
+ * order of tests/golden/glm_*: dot cross normalize reflect refract mix3 mix1 min3 max3 compmax compmin clamp01_sqrt
+ * near_zero length2 lerp radians) and fn 16 = Ray::at + isBackfacing (ray_data.cuh:14,44-46).  in = n * nin floats,
+ * out = n * nout floats in the layout of those fixtures.  Run by the GPU tests on the reference-generated vectors.   */
+int rt_probe_glm(int device, int fn, size_t n, const float* in, float* out);
+/* HOST probe (no GPU): the aabb helpers of the BVH builders — longest_axis, surface_area, centeroid, union, +=,
+ * box_{x,y,z}_compare (aabb.cuh:19,24,46-68,78-88): boxes n*12 (a.min a.max b.min b.max) -> out n*20.              */
+int rt_probe_aabb_misc(size_t n, const float* boxes, float* out);
+
 /* Verification probes for the fast exact division of the streaming kernel (csrc/rt_fastdiv.hpp).
  * rt_probe_aabb_regular: boxes n*6, rays n*6, max_dist n -> the "regular ray" classification n, and
  * hit/dist of the 5-instruction-division box test (only meaningful where regular == 1).             */

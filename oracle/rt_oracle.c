@@ -1308,3 +1308,58 @@ void orc_scene_free(orc_scene* s) {
     if (!s) return;
     free(s->prims); free(s->quads); free(s->mats); free(s->nodes); free(s->perlin); free(s->image); free(s);
 }
+
+/* ---- twins of the fixtures oracle/ref_path_probe.cpp generates from the reference's own headers (tests/golden/ref_*) ---- */
+/* aabb::longest_axis / surface_area / centeroid / union ctor / operator+= / box_{x,y,z}_compare (aabb.cuh:19,24,46-68,78-88):
+ * boxes n*12 (a.min a.max b.min b.max) -> out n*20 [axis, area, centroid 3, union min 3 max 3, a+=b min 3 max 3, cmp x y z] */
+void orc_aabb_misc_batch(size_t n, const float* boxes, float* out) {
+    for (size_t i = 0; i < n; i++) {
+        box_t a = {ld3(boxes + 12 * i), ld3(boxes + 12 * i + 3)}, b = {ld3(boxes + 12 * i + 6), ld3(boxes + 12 * i + 9)};
+        float* o = out + 20 * i;
+        o[0] = (float)box_longest_axis(a);
+        o[1] = box_surface_area(a);
+        st3(o + 2, box_centroid(a));
+        box_t u = box_union(a, b);
+        st3(o + 5, u.mn); st3(o + 8, u.mx);
+        box_t p = a; p = box_union(p, b);   /* operator+= is the same min/max with the operands in the same order */
+        st3(o + 11, p.mn); st3(o + 14, p.mx);
+        o[17] = a.mn.x < b.mn.x ? 1.0f : 0.0f;
+        o[18] = a.mn.y < b.mn.y ? 1.0f : 0.0f;
+        o[19] = a.mn.z < b.mn.z ? 1.0f : 0.0f;
+    }
+}
+/* checker_texture(c1, c2, scale)::value (cu_Textures.cuh:26-39): in n*10 (even 3, odd 3, scale, pos 3) -> colour n*3 */
+void orc_checker_batch(size_t n, const float* in, float* out) {
+    for (size_t i = 0; i < n; i++) {
+        orc_material m;
+        memset(&m, 0, sizeof(m));
+        memcpy(m.albedo, in + 10 * i, 12); memcpy(m.albedo2, in + 10 * i + 3, 12);
+        m.param = 1.0f / in[10 * i + 6];   /* inv_scale(1.0f / scale), cu_Textures.cuh:27 */
+        st3(out + 3 * i, checker_value(&m, ld3(in + 10 * i + 7)));
+    }
+}
+/* Ray::at (ray_data.cuh:14) and isBackfacing (ray_data.cuh:44-46): in n*10 (o, d, t, normal) -> out n*4 (at 3, backfacing) */
+void orc_ray_batch(size_t n, const float* in, float* out) {
+    for (size_t i = 0; i < n; i++) {
+        ray_t r; r.o = ld3(in + 10 * i); r.d = ld3(in + 10 * i + 3); r.time = 0.0f;
+        st3(out + 4 * i, ray_at(&r, in[10 * i + 6]));
+        out[4 * i + 3] = dot(r.d, ld3(in + 10 * i + 7)) > 0 ? 1.0f : 0.0f;
+    }
+}
+/* leaf tests / box tests of one trace per ray (the instrumented counters of the render loop, per ray) */
+int orc_trace_counts(const orc_world* w, size_t n, const float* rays, uint32_t* out_leaf_tests, uint32_t* out_box_tests) {
+    int err = 0;
+    for (size_t i = 0; i < n; i++) {
+        ray_t r = ld_ray7(rays + 7 * i);
+        rec_t rec;
+        memset(&rec, 0, sizeof(rec));
+        rec.distance = ORC_MISS_DIST; rec.prim = -1;
+        orc_counters c;
+        memset(&c, 0, sizeof(c));
+        rng_t g;
+        rng_init(&g, 0u, (uint32_t)i, 0u, 0x7ACEu);
+        world_closest_intersection(w, &r, &rec, &c, &err, &g);
+        out_leaf_tests[i] = (uint32_t)c.leaf_tests; out_box_tests[i] = (uint32_t)c.box_tests;
+    }
+    return err;
+}

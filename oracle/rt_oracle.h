@@ -125,6 +125,12 @@ int  orc_radiance_batch(const orc_world* w, const orc_camera* cam, uint32_t widt
 void orc_sphere_index(const orc_camera* cam, uint32_t width, uint32_t height, size_t n_spheres,
                       const float* spheres, int32_t* out_index);
 
+/* twins of the fixtures generated from the reference's own aabb / texture / ray_data headers (tests/golden/ref_*) */
+void orc_aabb_misc_batch(size_t n, const float* boxes, float* out);
+void orc_checker_batch(size_t n, const float* in, float* out);
+void orc_ray_batch(size_t n, const float* in, float* out);
+int  orc_trace_counts(const orc_world* w, size_t n, const float* rays, uint32_t* out_leaf_tests, uint32_t* out_box_tests);
+
 /* ---- cameras (constructors) ---- */
 void orc_camera_pinhole(const float lookfrom[3], const float lookat[3], const float up[3],
                         float vfov, float aspect, orc_camera* out);

@@ -365,6 +365,29 @@ def probe_math(fn, a, b=None, device=0):
     return out
 
 
+GLM_FUNCTIONS = ("dot", "cross", "normalize", "reflect", "refract", "mix3", "mix1", "min3", "max3", "compmax", "compmin",
+                 "clamp01_sqrt", "near_zero", "length2", "lerp", "radians", "ray")
+_GLM_SHAPES = ((6, 1), (6, 3), (3, 3), (6, 3), (7, 3), (7, 3), (3, 1), (6, 3), (6, 3), (3, 1), (3, 1), (3, 3), (3, 1), (3, 1), (7, 3), (1, 1), (10, 4))
+
+
+def probe_glm(name, inputs, device=0):
+    """rt_probe_glm: one function of the device math vocabulary (GLM_FUNCTIONS) over an (n, nin) array -> (n, nout)."""
+    fn = GLM_FUNCTIONS.index(name)
+    nin, nout = _GLM_SHAPES[fn]
+    a = np.ascontiguousarray(inputs, np.float32).reshape(-1, nin)
+    out = np.zeros((len(a), nout), np.float32)
+    check(lib().rt_probe_glm(device, fn, len(a), a, out))
+    return out
+
+
+def probe_aabb_misc(boxes):
+    """rt_probe_aabb_misc (host): (n, 12) boxes a, b -> (n, 20) [axis, area, centroid, union, a += b, compares]."""
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 12)
+    out = np.zeros((len(b), 20), np.float32)
+    check(lib().rt_probe_aabb_misc(len(b), b, out))
+    return out
+
+
 def device_count():
     n = C.c_int()
     check(lib().rt_device_count(C.byref(n)))

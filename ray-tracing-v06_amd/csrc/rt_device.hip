@@ -729,25 +729,35 @@ __global__ void probe_radiance_kernel(DeviceWorld w, rt_camera cam, uint32_t wid
     f3 rad = one_sample(w, cam, width, height, max_depth, seed, keys[2 * i], keys[2 * i + 1]);
     st3(out + 3 * i, rad);
 }
-// google_testing/test.cpp:112-135 (_sphere_index_ker)
-__global__ void probe_sphere_index_kernel(const float* spheres, int sphere_count, rt_camera cam, int width, int height, int32_t* results) {
-    int x_id = blockDim.x * blockIdx.x + threadIdx.x;
-    int y_id = blockDim.y * blockIdx.y + threadIdx.y;
-    if (x_id >= width || y_id >= height) return;
-    int gid = y_id * width + x_id;
-    float u = (float)x_id / ((float)width - 1.0f) * 2 - 1;
-    float v = (float)y_id / ((float)height - 1.0f) * 2 - 1;
+// The reference's one gtest computes, per pixel, the index of the nearest sphere by brute force (google_testing/test.cpp:112-135,
+// host twin :87-106).  Here: one work-item per pixel of a flat index space, the sphere table staged through the LDS in slabs of
+// 256 so that the 64 lanes of a wave read each sphere as a broadcast; NDC = i / (extent - 1) * 2 - 1 is that test's convention
+// (test.cpp:118-119), not the renderer's pixel-centre one.
+__global__ __launch_bounds__(256) void probe_sphere_index_kernel(const float4* __restrict__ spheres, uint32_t n_spheres, rt_camera cam,
+                                                                 uint32_t width, uint32_t height, int32_t* __restrict__ nearest) {
+    __shared__ float4 slab[256];
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    const bool live = pixel < width * height;
+    const uint32_t px = live ? pixel % width : 0u, py = live ? pixel / width : 0u;
     Ray ray;
     ray.o = mk3(cam.o[0], cam.o[1], cam.o[2]);
-    ray.d = mk3(cam.w[0], cam.w[1], cam.w[2]) + mk3(cam.u[0], cam.u[1], cam.u[2]) * u + mk3(cam.v[0], cam.v[1], cam.v[2]) * v;
+    const float s = (float)px / ((float)width - 1.0f) * 2 - 1, t = (float)py / ((float)height - 1.0f) * 2 - 1;
+    ray.d = mk3(cam.w[0], cam.w[1], cam.w[2]) + mk3(cam.u[0], cam.u[1], cam.u[2]) * s + mk3(cam.v[0], cam.v[1], cam.v[2]) * t;
     ray.time = 0.0f;
-    float best = RT_MISS_DIST;
-    int result_index = -1;
-    for (int i = 0; i < sphere_count; i++) {
-        float dist = sphere_closest_intersection(ray, ld3(spheres + 4 * i), spheres[4 * i + 3]);
-        if (dist < best) { result_index = i; best = dist; }
+    float nearest_t = RT_MISS_DIST;
+    int32_t winner = -1;
+    for (uint32_t base = 0; base < n_spheres; base += 256u) {
+        const uint32_t count = min(256u, n_spheres - base);
+        __syncthreads();
+        if (threadIdx.x < count) slab[threadIdx.x] = spheres[base + threadIdx.x];
+        __syncthreads();
+        for (uint32_t k = 0; k < count; k++) {
+            const float4 sp = slab[k];
+            const float tk = sphere_closest_intersection(ray, mk3(sp.x, sp.y, sp.z), sp.w);
+            if (tk < nearest_t) { nearest_t = tk; winner = (int32_t)(base + k); }   // strict: the first of equal distances wins
+        }
     }
-    results[gid] = result_index;
+    if (live) nearest[pixel] = winner;
 }
 __global__ void probe_rng_kernel(uint64_t seed, size_t n, const uint32_t* keys, uint32_t n_draws, float* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -871,9 +881,8 @@ extern "C" int rt_probe_sphere_index(int device, const rt_camera* cam, uint32_t 
     DevBuf s, o;
     UP(s, spheres, n_spheres * 16);
     HIP_TRY(o.alloc((size_t)width * height * 4));
-    dim3 threads(8, 8, 1);  // test.cpp:153-155
-    dim3 blocks((width + 7) / 8, (height + 7) / 8, 1);
-    probe_sphere_index_kernel<<<blocks, threads>>>(s.as<float>(), (int)n_spheres, *cam, (int)width, (int)height, o.as<int32_t>());
+    if (n_spheres > 0x7fffffffull || (uint64_t)width * height > 0xffffff00ull) return rt_fail(RT_ERR_INVALID, "rt_probe_sphere_index: too large");
+    probe_sphere_index_kernel<<<(width * height + 255u) / 256u, 256>>>(s.as<float4>(), (uint32_t)n_spheres, *cam, width, height, o.as<int32_t>());
     FINISH();
     DOWN(out_index, o, (size_t)width * height * 4);
     return RT_OK;
@@ -910,6 +919,56 @@ extern "C" int rt_probe_math(int device, int fn, size_t n, const float* a, const
     probe_math_kernel<<<PROBE_GRID(n)>>>(fn, n, da.as<float>(), db.as<float>(), o.as<float>());
     FINISH();
     DOWN(out, o, n * 4);
+    return RT_OK;
+}
+
+// The device half of the math vocabulary (csrc/rt_math.hpp) over arrays: the functions the fixtures tests/golden/glm_*.f32 —
+// generated by the REFERENCE's vendored GLM + glm_utils.h (oracle/ref_glm_probe.cpp) — cover, plus Ray::at / isBackfacing
+// (tests/golden/ref_ray_*, from the reference's ray_data.cuh).  The one direct reference -> HIP check there is.
+__global__ void probe_glm_kernel(int fn, size_t n, uint32_t nin, uint32_t nout, const float* __restrict__ in, float* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + i * nin;
+    float* o = out + i * nout;
+    switch (fn) {
+        case 0: o[0] = dot(ld3(a), ld3(a + 3)); break;
+        case 1: st3(o, cross(ld3(a), ld3(a + 3))); break;
+        case 2: st3(o, normalize(ld3(a))); break;
+        case 3: st3(o, reflect(ld3(a), ld3(a + 3))); break;
+        case 4: st3(o, refract(ld3(a), ld3(a + 3), a[6])); break;
+        case 5: st3(o, mix(ld3(a), ld3(a + 3), a[6])); break;
+        case 6: o[0] = mix(a[0], a[1], a[2]); break;
+        case 7: st3(o, glm_min(ld3(a), ld3(a + 3))); break;
+        case 8: st3(o, glm_max(ld3(a), ld3(a + 3))); break;
+        case 9: o[0] = comp_max(ld3(a)); break;
+        case 10: o[0] = comp_min(ld3(a)); break;
+        case 11: st3(o, clamp01_sqrt(ld3(a))); break;
+        case 12: o[0] = near_zero(ld3(a)) ? 1.0f : 0.0f; break;
+        case 13: o[0] = length2(ld3(a)); break;
+        case 14: st3(o, linear_interpolate(ld3(a), ld3(a + 3), a[6])); break;
+        case 15: o[0] = radians(a[0]); break;
+        default: {  // 16: Ray::at (ray_data.cuh:14) + isBackfacing (ray_data.cuh:44-46): (o, d, t, normal) -> (at, backfacing)
+            Ray r; r.o = ld3(a); r.d = ld3(a + 3); r.time = 0.0f;
+            st3(o, ray_at(r, a[6]));
+            o[3] = dot(r.d, ld3(a + 7)) > 0 ? 1.0f : 0.0f;
+        }
+    }
+}
+extern "C" int rt_probe_glm(int device, int fn, size_t n, const float* in, float* out) {
+    static const uint32_t shape[17][2] = {{6, 1}, {6, 3}, {3, 3}, {6, 3}, {7, 3}, {7, 3}, {3, 1}, {6, 3}, {6, 3}, {3, 1}, {3, 1}, {3, 3}, {3, 1},
+                                          {3, 1}, {7, 3}, {1, 1}, {10, 4}};
+    if (!in || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_glm: null argument");
+    if (fn < 0 || fn > 16) return rt_fail(RT_ERR_INVALID, "rt_probe_glm: unknown function %d", fn);
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    const uint32_t nin = shape[fn][0], nout = shape[fn][1];
+    DevBuf di, dout;
+    UP(di, in, n * nin * 4);
+    HIP_TRY(dout.alloc(n * nout * 4));
+    probe_glm_kernel<<<PROBE_GRID(n)>>>(fn, n, nin, nout, di.as<float>(), dout.as<float>());
+    FINISH();
+    DOWN(out, dout, n * nout * 4);
     return RT_OK;
 }
 

@@ -101,6 +101,27 @@ static f3 box_centroid(const Box& b) { return (b.mx + b.mn) * 0.5f; }           
 static float axis_of(f3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
 
 // getSphereBounds / getMovingSphereBounds, SphereHittable.cu:52-54, 85-89
+// Host probe: the aabb helpers the builders are made of (aabb.cuh:19,24,46-68,78-88), over arrays — checked against fixtures
+// generated from the reference's own aabb.cuh (tests/golden/ref_aabbmisc_*).  boxes n*12 (a.min a.max b.min b.max) ->
+// out n*20 [longest axis, surface area, centroid 3, union min 3 max 3, a += b min 3 max 3, a.min < b.min per axis 3]
+extern "C" int rt_probe_aabb_misc(size_t n, const float* boxes, float* out) {
+    if (!boxes || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_aabb_misc: null argument");
+    for (size_t i = 0; i < n; i++) {
+        const Box a{ld3(boxes + 12 * i), ld3(boxes + 12 * i + 3)}, b{ld3(boxes + 12 * i + 6), ld3(boxes + 12 * i + 9)};
+        float* o = out + 20 * i;
+        o[0] = (float)box_longest_axis(a);
+        o[1] = box_surface_area(a);
+        st3(o + 2, box_centroid(a));
+        const Box u = box_union(a, b);
+        st3(o + 5, u.mn); st3(o + 8, u.mx);
+        Box acc = a;
+        acc = box_union(acc, b);
+        st3(o + 11, acc.mn); st3(o + 14, acc.mx);
+        o[17] = a.mn.x < b.mn.x ? 1.0f : 0.0f; o[18] = a.mn.y < b.mn.y ? 1.0f : 0.0f; o[19] = a.mn.z < b.mn.z ? 1.0f : 0.0f;
+    }
+    return RT_OK;
+}
+
 static Box prim_bounds(const rt_prim& p) {
     f3 r = mk3(p.radius);
     Box b0{ld3(p.c0) - r, ld3(p.c0) + r};
