@@ -11,10 +11,15 @@ the frame over the ranks (one process per GPU), each rank renders its shard, ONE
 shards to rank 0 over xGMI and a de-interleave kernel assembles the image.  Total work is fixed as N
 grows ("strong" scaling).  Rank 0 prints one JSON line.
 
-`roofline` prices the dominant kernel against HBM with SURVEY.md §8(d)'s ALGORITHMIC bytes per sample
-(32 B per box test + 16 B per sphere test + 16 B per shaded hit + 16/spp B of framebuffer), the counts
-measured by the instrumented CPU oracle on the same scene and seed.  `cpu_baseline` times that oracle (a
-CPU port of the loop — the reference has no CPU renderer) on the host cores, on a bounded spp.
+`roofline` reports the resource that BINDS the dominant kernel (render_kernel_stream): vector-instruction issue.  The scene
+is LDS-resident, so HBM is not the roof — `roofline.hbm` keeps SURVEY.md §8(d)'s algorithmic-bytes figure (32 B per box test
++ 16 B per sphere test + 16 B per shaded hit + 16/spp B, counts from the instrumented CPU oracle on the same scene and
+seed) and the measured HBM traffic as secondary, clearly labelled fields.  achieved = wave-instructions per launch
+(SQ_INSTS_VALU of the committed rocprofv3 counter pass, profiles/rNN_bench_pmc_summary.csv, stamped with the hash of the
+sources it was taken from and marked stale when that is not the running library) / the kernel's duration measured LIVE in
+this run with HIP events on the stream it runs on; peak = SIMDs x clock / 2 (one fp32 add / mul / fma wave-instruction per
+2 cycles per SIMD, tools/bench_valu_issue.hip); frac <= 1.  `cpu_baseline` times the oracle (a CPU port of the loop — the
+reference has no CPU renderer) on the host cores, on a bounded spp.
 """
 import argparse
 import json
@@ -78,9 +83,12 @@ def parse():
                     help="frames in flight: 2 renders frame k+1 on a second HIP stream while frame k drains its last paths and is gathered "
                          "(two renderers, two shard buffers; the collectives stay on one stream, in order); 1 = strictly serial; "
                          "0 (default) = 1.  Measured: no gain on one GPU (a persistent workgroup frees its LDS only when its last wave "
-                         "ends, so the next frame cannot move in early); on several GPUs it hides the gather behind the next render")
-    ap.add_argument("--verify-assembly", action="store_true",
-                    help="N > 1: after the timed region rank 0 renders the frame alone and requires the assembled image to be the same bits")
+                         "ends, so the next frame cannot move in early); on several GPUs it is EXPECTED to hide the gather behind the next "
+                         "render — unmeasured: no multi-GPU hardware run has been recorded yet")
+    ap.add_argument("--verify-assembly", dest="verify_assembly", action="store_true", default=True,
+                    help="N > 1 (default on): after the timed region rank 0 renders the frame alone and requires the assembled image to be the "
+                         "same bits; the JSON line carries assembly_verified")
+    ap.add_argument("--no-verify-assembly", dest="verify_assembly", action="store_false")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
     a.width = a.width or wl[4]
@@ -102,47 +110,48 @@ def host_cores():
     return n
 
 
-def profiled_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 PMC summary
-    (profiles/rNN_bench_pmc_summary.csv: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this same command).
-    MI355X_MICROARCH.md §HBM: both counters are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request on
-    wide coalesced reads, so it is doubled.  Returns (bytes, source) or (None, None)."""
+def profiled_counters(kernel_substr):
+    """Per-launch hardware counters of the dominant kernel from the newest committed rocprofv3 summary
+    (profiles/rNN_bench_pmc_summary.csv: separate --pmc passes of this same command, tools/profile_round.sh).
+    Returns (counters dict, relative path, source hash the file was stamped with) or (None, None, None)."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_summary.csv")))
     if not files:
-        return None, None
-    vals = {}
-    for row in csv.DictReader(open(files[-1])):
-        if kernel_substr in row["kernel"] and row["counter"] in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals[row["counter"]] = float(row["mean_per_dispatch"])
-    if len(vals) != 2:
-        return None, None
-    return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
-
-
-def profiled_valu(kernel_substr):
-    """What actually bounds the kernel (VALU issue), from the same committed PMC summary: wave-instructions per
-    launch, fraction of the VALU issue peak (one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, at the clock
-    GRBM_GUI_ACTIVE / 8 XCDs measured for that launch) and mean fraction of the 64 lanes active per instruction."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_summary.csv")))
-    if not files:
-        return None
+        return None, None, None
+    lines = open(files[-1]).read().splitlines()
+    stamp = None
+    while lines and lines[0].startswith("#"):
+        if "csrc_sha256:" in lines[0]:
+            stamp = lines[0].split("csrc_sha256:")[1].strip()
+        lines.pop(0)
     v = {}
-    for row in csv.DictReader(open(files[-1])):
+    for row in csv.DictReader(lines):
         if kernel_substr in row["kernel"]:
             v[row["counter"]] = float(row["mean_per_dispatch"])
-    need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE")
-    if any(k not in v for k in need):
+    return (v or None), os.path.relpath(files[-1], ROOT), stamp
+
+
+def issue_roofline(v, kernel_ms, n_simd, clock_ghz):
+    """The binding roof: vector-instruction issue.  achieved = SQ_INSTS_VALU / live kernel time; peak = one wave-instruction per
+    2 cycles per SIMD at the device's peak engine clock (an upper bound of the clock the launch ran at, so frac is a lower
+    bound of the issue utilisation at the actual clock)."""
+    need = ("SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU")
+    if v is None or any(k not in v for k in need):
         return None
-    cycles = v["GRBM_GUI_ACTIVE"] / 8.0
-    out = {"wave_instructions_per_launch": v["SQ_INSTS_VALU"],
-           "issue_frac_of_peak": round(v["SQ_INSTS_VALU"] / (1024.0 * cycles * 0.5), 4),
-           "lanes_active_frac": round(v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0), 4)}
+    achieved = v["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9
+    peak = n_simd * clock_ghz / 2.0
+    lanes = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_INSTS_VALU"] * 64.0)
+    out = {"achieved": round(achieved, 2), "peak": round(peak, 2), "unit": "G wave-instructions/s", "frac": round(achieved / peak, 4),
+           "wave_instructions_per_launch": v["SQ_INSTS_VALU"], "lanes_active_frac": round(lanes, 4),
+           "lane_weighted_frac": round(achieved / peak * lanes, 4)}
     if "SQ_INSTS_SALU" in v:
         out["scalar_instructions_per_launch"] = v["SQ_INSTS_SALU"]
+    if "SQ_LDS_IDX_ACTIVE" in v and "GRBM_GUI_ACTIVE" in v:
+        cu_cycles = v["GRBM_GUI_ACTIVE"] / 8.0 * (n_simd / 4.0)   # GRBM_GUI_ACTIVE sums the 8 XCDs
+        out["lds_busy_frac"] = round(v["SQ_LDS_IDX_ACTIVE"] / cu_cycles, 4)
+        if "SQ_LDS_BANK_CONFLICT" in v:
+            out["lds_bank_conflict_frac_of_busy"] = round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 4)
     return out
 
 
@@ -184,9 +193,16 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
     parity = None
     if gpu_image_fn is not None:
         img = gpu_image_fn(spp)
+        nan_mismatch = int(np.count_nonzero(np.isnan(img[..., :3]) != np.isnan(ref[..., :3])))   # NaN on one side only is a failure
         d = np.abs(img[..., :3] - ref[..., :3])
-        parity = {"max_abs_delta": float(np.nanmax(d)), "mean_abs_delta": float(np.nanmean(d)),
+        both = ~np.isnan(d)
+        parity = {"max_abs_delta": float(d[both].max()) if both.any() else float("nan"),
+                  "mean_abs_delta": float(d[both].mean()) if both.any() else float("nan"),
+                  "nan_mismatch": nan_mismatch, "nan_pixels_both": int(np.count_nonzero(np.isnan(img[..., :3]).any(-1) & np.isnan(ref[..., :3]).any(-1))),
+                  "bit_identical": bool(nan_mismatch == 0 and np.all((img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref)))),
                   "tolerance": 1e-3, "sample": f"{W}x{H}x{spp}spp GPU vs CPU oracle, same seed"}
+        if nan_mismatch or not (parity["max_abs_delta"] < 1e-3):
+            raise SystemExit(f"parity failed: {parity}")
     return base, counts, parity
 
 
@@ -277,18 +293,16 @@ def main():
         elapsed = float(t.item())
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_events])) if kernel_events else float("nan")
     kernel_ms_source = "HIP events around every launch of the timed region"
-    if depth > 1:
-        # frames overlap inside the timed region, so an event pair there spans the wait for the previous frame's workgroups too:
-        # take the kernel's duration from ONE more launch on the drained GPU (untimed, after the timed region)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        rs[0].render_async(stream.cuda_stream, (images[0] if world_size == 1 else shards[0]).data_ptr())
-        e1.record(stream)
-        torch.cuda.synchronize()
-        kernel_ms = float(e0.elapsed_time(e1))
-        kernel_ms_source = "one serial launch after the timed region (two frames are in flight inside it)"
-        if world_size > 1:
-            dist.barrier()
+    # per-kernel durations of the timed steps: HIP events the renderer records on the stream its kernels run on (ring of 32 renders)
+    per_kernel = []
+    if args.variant != 1:
+        n_back = min(args.steps, 32 * depth)
+        for k in range(n_back):
+            rr = rs[(frame[0] - 1 - k) % depth]
+            per_kernel.append(rr.kernel_times(k // depth))
+    primary_ms, stream_ms, resolve_ms = (float(np.mean([t[i] for t in per_kernel])) for i in range(3)) if per_kernel else (float("nan"),) * 3
+    if world_size > 1:
+        dist.barrier()
 
     total_samples = float(W) * H * spp
     out = None
@@ -314,27 +328,41 @@ def main():
                        "parallelism": f"tile-shard x{world_size} + 1 RCCL gather" if world_size > 1 else "single GPU",
                        "frames_in_flight": depth,
                        "kernel_variant": args.variant},
-            "kernel_ms_per_step_rank0": round(kernel_ms, 3), "kernel_ms_source": kernel_ms_source,
+            "kernel_ms_per_step_rank0": round(kernel_ms, 3), "kernel_ms_source": kernel_ms_source + " (all kernels of a step)",
         }
         if counts is None:
             counts = count_leg(args)
         if counts is not None:
             bytes_per_sample = 32.0 * counts["box_tests"] + 16.0 * counts["leaf_tests"] + 16.0 * counts["shaded_hits"] + 16.0 / spp
             launch_samples = total_samples / world_size
-            achieved = bytes_per_sample * launch_samples / (kernel_ms * 1e-3) / 1e9
             default_cfg = (args.workload, W, H, spp, args.depth, args.variant, world_size) == ("book1_final", 1200, 800, 500, 50, 0, 1)
-            traffic, traffic_src = profiled_traffic("render_kernel_stream") if default_cfg else (None, None)
-            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                               "kernel": "render_kernel_stream", "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
-                               "samples_per_launch": launch_samples, "kernel_ms": round(kernel_ms, 3),
-                               "counts_per_sample": {k: round(v, 3) for k, v in counts.items()},
-                               "traffic_source": traffic_src,
-                               "valu": profiled_valu("render_kernel_stream") if default_cfg else None,
-                               "note": "algorithmic bytes = BVH node / sphere / material records the traversal touches; they are "
-                                       "served from the LDS-resident scene, not HBM, so frac can exceed 1 and measured HBM traffic "
-                                       "(the 12-B-per-sample radiance buffer) is ~250x smaller: the kernel is instruction-issue bound (the peak of issue_frac_of_peak is the 2-cycle fp32 add/mul/fma rate; compares, selects, min/max cost 4 cycles and scalar instructions are not hidden) "
-                                       "(DESIGN.md §7)"}
+            pmc, pmc_src, pmc_stamp = profiled_counters("render_kernel_stream") if default_cfg else (None, None, None)
+            info = pkg.api.device_info(local_rank)
+            n_simd, clock_ghz = info["compute_units"] * 4, info["clock_khz"] / 1e6
+            roof = issue_roofline(pmc, stream_ms, n_simd, clock_ghz) or {"achieved": None, "peak": round(n_simd * clock_ghz / 2.0, 2),
+                                                                          "unit": "G wave-instructions/s", "frac": None}
+            traffic = None
+            if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                # MI355X_MICROARCH.md, HBM section: both counters are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request on wide reads
+                traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            lib_hash = pkg.capi.source_hash()
+            out["roofline"] = {
+                "bound": "valu_issue", "kernel": "render_kernel_stream", **roof, "traffic": traffic,
+                "kernel_ms": round(stream_ms, 3), "kernel_ms_source": "HIP events on the kernel's stream, mean over the timed steps (rt_renderer_kernel_times)",
+                "other_kernels_ms": {"primary_rays_kernel": round(primary_ms, 3), "resolve_kernel": round(resolve_ms, 3)},
+                "peak_definition": f"{n_simd} SIMDs x {clock_ghz:.3f} GHz / 2 cycles per wave64 fp32 add/mul/fma (tools/bench_valu_issue.hip); compares, selects, min/max "
+                                   "issue in 4 cycles and scalar instructions are not hidden, so frac = 1 is not reachable by this instruction mix",
+                "samples_per_launch": launch_samples,
+                "counters_source": pmc_src, "counters_source_csrc_sha256": pmc_stamp, "library_csrc_sha256": lib_hash,
+                "counters_stale": (None if pmc_src is None else bool(pmc_stamp != lib_hash)),
+                "counts_per_sample": {k: round(v, 3) for k, v in counts.items()},
+                "hbm": {"note": "secondary: the scene (60 KB) is LDS-resident, the algorithmic bytes are served from the LDS and HBM is not the roof",
+                        "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+                        "algorithmic_GBps": round(bytes_per_sample * launch_samples / (stream_ms * 1e-3) / 1e9, 1),
+                        "measured_bytes_per_launch": traffic,
+                        "measured_GBps": None if traffic is None else round(traffic / (stream_ms * 1e-3) / 1e9, 1),
+                        "peak_GBps": HBM_PEAK_GBS,
+                        "measured_frac_of_peak": None if traffic is None else round(traffic / (stream_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
             if base is not None:
                 out["cpu_baseline"] = base
             if parity is not None:

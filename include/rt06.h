@@ -281,6 +281,10 @@ int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float* d_out);
 /* HIP-event time of the last render launch(es) in ms (cudaTimer twin,
  * Renderer.cu:127-136).  Synchronises on the events.                        */
 int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms);
+/* Per-kernel HIP-event times (ms) of one of the last 32 render calls (renders_back = 0: the most recent), measured on the
+ * stream the kernels ran on: out[0] = primary_rays_kernel, out[1] = render_kernel_stream (the dominant kernel),
+ * out[2] = resolve_kernel — of the call's last pass.  Synchronises on that call's end.  Streaming variants (>= 2) only. */
+int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms[3]);
 /* Which kernel the renderer resolved to: out[0] = variant actually used (1..4), out[1] = 1 when the scene image is
  * LDS-resident (0: baseline kernel, or a world too large for the LDS, served from global memory / L2 with 32-bit
  * references), out[2] = workgroup size, out[3] = workgroups per CU.                                              */
@@ -294,6 +298,31 @@ int rt_renderer_shard_floats(const rt_renderer* r, size_t* out);
 /* Rank-0 side of the frame-end gather: `d_gathered` holds world_size shards
  * back to back (rank-major); writes the row-major width*height*4 image.     */
 int rt_renderer_assemble(rt_renderer* r, const float* d_gathered, float* d_image, void* hip_stream);
+
+/* ------------------------------------------------------------------ */
+/* Multi-GPU renderer — the same three entry points (Renderer.h:38-46)  */
+/* over the N GPUs of one node, driven by ONE host process.            */
+/* ------------------------------------------------------------------ */
+/* The reference is single-GPU.  Rank i = devices[i] (NULL: 0 .. n_gpus-1) renders the 8x8 tiles t with
+ * t % n_gpus == i; ONE grouped RCCL exchange over xGMI (ncclSend from every rank, ncclRecv on rank 0) gathers the shards
+ * on devices[0] at frame end and a de-interleave kernel assembles the row-major frame there.  cfg->device / rank /
+ * world_size are ignored.  The image has the same bits for every n_gpus.  RCCL (librccl.so.1) is bound at first use.    */
+typedef struct rt_multi_renderer rt_multi_renderer;
+int rt_multi_renderer_create(const rt_render_config* cfg, const rt_camera* cam, const rt_world_flat* world,
+                             uint32_t n_gpus, const int32_t* devices, rt_multi_renderer** out);
+void rt_multi_renderer_destroy(rt_multi_renderer* m);
+/* Renderer::Render: blocking; renders all shards side by side, gathers, assembles.                                      */
+int rt_multi_renderer_render(rt_multi_renderer* m);
+/* Renderer::DownloadRenderbuffer: width*height*4 floats from devices[0].                                                */
+int rt_multi_renderer_download(rt_multi_renderer* m, float* host_rgba, size_t n_floats);
+/* ms of the last render: out[0] host wall-clock of Render(), out[1] slowest rank's kernels (HIP events),
+ * out[2] exchange + assembly on devices[0] (HIP events)                                                                 */
+int rt_multi_renderer_times(rt_multi_renderer* m, float out_ms[3]);
+int rt_multi_renderer_gpus(const rt_multi_renderer* m, uint32_t* out);
+/* HOST (no GPU): the shard layout every rank uses — out = {tiles_x, n_tiles, n_local_tiles, shard_floats} — and the global
+ * pixel id of every shard position of one rank (n = n_local_tiles * 64 entries, 0xffffffff for padding).                */
+int rt_shard_layout(uint32_t width, uint32_t height, uint32_t world_size, uint32_t out[4]);
+int rt_shard_pixel_map(uint32_t width, uint32_t height, uint32_t world_size, uint32_t rank, uint32_t* out_gid, size_t n);
 
 /* ------------------------------------------------------------------ */
 /* Device probes: run ONE hot-path function over an array of inputs on  */
@@ -371,6 +400,8 @@ int rt_selftest_fastrcp(int device, uint64_t* checked, uint64_t* mismatches, uin
 
 /* library / device info */
 int rt_device_count(int* out);
+/* out = {compute units, peak engine clock in kHz, device memory in MiB, memory clock in kHz} (hipDeviceProp_t) */
+int rt_device_info(int device, uint32_t out[4]);
 const char* rt_version(void);
 
 #ifdef __cplusplus

@@ -453,11 +453,13 @@ class Renderer {
     struct M {
         uint32_t render_width{}, render_height{};
         uint32_t samples_per_pixel{}, max_depth{};
-        rt_renderer* r{};
+        rt_renderer* r{};          // one GPU
+        rt_multi_renderer* mr{};   // n_gpus > 1: tile shards on every GPU, one RCCL gather at frame end
     } m;
     explicit Renderer(M mm) : m(mm) {}
     Renderer(const Renderer&) = delete;
     Renderer& operator=(const Renderer&) = delete;
+    void destroy() { rt_renderer_destroy(m.r); rt_multi_renderer_destroy(m.mr); m.r = nullptr; m.mr = nullptr; }
 
     static void flatten(const Hittable* world, rt06::SceneBuilder& tmp, rt_world_flat& w) {
         switch (world->kind()) {
@@ -478,7 +480,8 @@ class Renderer {
         }
         rt06::check(rt_scene_get_flat(tmp.get(), &w), "rt_scene_get_flat");
     }
-    static Renderer make(uint32_t w_, uint32_t h_, uint32_t spp, uint32_t depth, const rt_camera& cam, const Hittable* world, uint64_t seed, int device) {
+    static Renderer make(uint32_t w_, uint32_t h_, uint32_t spp, uint32_t depth, const rt_camera& cam, const Hittable* world, uint64_t seed, int device,
+                         uint32_t n_gpus) {
         if (!world) throw std::runtime_error("Renderer::MakeRenderer: null world");
         rt06::SceneBuilder tmp;
         rt_world_flat wf;
@@ -488,38 +491,46 @@ class Renderer {
         cfg.seed = seed; cfg.device = device; cfg.rank = 0; cfg.world_size = 1; cfg.variant = 0;
         M mm;
         mm.render_width = w_; mm.render_height = h_; mm.samples_per_pixel = spp; mm.max_depth = depth;
-        rt06::check(rt_renderer_create(&cfg, &cam, &wf, &mm.r), "Renderer::MakeRenderer");
+        if (n_gpus > 1) rt06::check(rt_multi_renderer_create(&cfg, &cam, &wf, n_gpus, nullptr, &mm.mr), "Renderer::MakeRenderer");
+        else rt06::check(rt_renderer_create(&cfg, &cam, &wf, &mm.r), "Renderer::MakeRenderer");
         return Renderer(mm);
     }
 
 public:
-    ~Renderer() { rt_renderer_destroy(m.r); }
-    Renderer(Renderer&& o) : m(o.m) { o.m.r = nullptr; }
+    ~Renderer() { destroy(); }
+    Renderer(Renderer&& o) : m(o.m) { o.m.r = nullptr; o.m.mr = nullptr; }
     Renderer& operator=(Renderer&& o) {
-        if (this != &o) { rt_renderer_destroy(m.r); m = o.m; o.m.r = nullptr; }
+        if (this != &o) { destroy(); m = o.m; o.m.r = nullptr; o.m.mr = nullptr; }
         return *this;
     }
     // The reference takes `const MotionBlurCamera*`; the other two camera types are accepted as well.
-    // seed: the reference hard-codes 1984 (Renderer.cu:51).
+    // seed: the reference hard-codes 1984 (Renderer.cu:51).  n_gpus > 1: the frame is tile-sharded over GPUs 0 .. n_gpus-1 of the
+    // node and gathered on GPU 0 with one RCCL exchange (rt_multi_renderer_*); the image is the same for every n_gpus.
     static Renderer MakeRenderer(uint32_t render_width, uint32_t render_height, uint32_t samples_per_pixel, uint32_t max_depth,
-                                 const MotionBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0) {
-        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device);
+                                 const MotionBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1) {
+        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus);
     }
     static Renderer MakeRenderer(uint32_t render_width, uint32_t render_height, uint32_t samples_per_pixel, uint32_t max_depth,
-                                 const DefocusBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0) {
-        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device);
+                                 const DefocusBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1) {
+        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus);
     }
     static Renderer MakeRenderer(uint32_t render_width, uint32_t render_height, uint32_t samples_per_pixel, uint32_t max_depth,
-                                 const PinholeCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0) {
-        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device);
+                                 const PinholeCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1) {
+        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus);
     }
-    void Render() { rt06::check(rt_renderer_render(m.r), "Renderer::Render"); }
+    void Render() {
+        if (m.mr) rt06::check(rt_multi_renderer_render(m.mr), "Renderer::Render");
+        else rt06::check(rt_renderer_render(m.r), "Renderer::Render");
+    }
     float LastKernelMs() {
         float ms = 0;
+        if (m.mr) { float t[3]; rt06::check(rt_multi_renderer_times(m.mr, t), "Renderer::LastKernelMs"); return t[0]; }
         rt06::check(rt_renderer_last_kernel_ms(m.r, &ms), "Renderer::LastKernelMs");
         return ms;
     }
     void DownloadRenderbuffer(glm::vec4* host_dst) const {
-        rt06::check(rt_renderer_download(m.r, reinterpret_cast<float*>(host_dst), (size_t)m.render_width * m.render_height * 4), "Renderer::DownloadRenderbuffer");
+        const size_t n = (size_t)m.render_width * m.render_height * 4;
+        if (m.mr) rt06::check(rt_multi_renderer_download(m.mr, reinterpret_cast<float*>(host_dst), n), "Renderer::DownloadRenderbuffer");
+        else rt06::check(rt_renderer_download(m.r, reinterpret_cast<float*>(host_dst), n), "Renderer::DownloadRenderbuffer");
     }
 };

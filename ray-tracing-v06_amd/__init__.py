@@ -5,5 +5,5 @@ include/rt06.h, built into csrc/librt06.so) and the host-side mirror of the refe
 The directory name is not a Python identifier; load it with __graft_entry__.load_package().
 """
 from . import api, capi  # noqa: F401  (multigpu imports torch; import it explicitly where needed)
-from .api import (DefocusBlurCamera, MotionBlurCamera, PinholeCamera, Renderer, Scene)  # noqa: F401
+from .api import (DefocusBlurCamera, MotionBlurCamera, MultiRenderer, PinholeCamera, Renderer, Scene)  # noqa: F401
 from .capi import build_native, lib  # noqa: F401

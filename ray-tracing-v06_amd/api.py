@@ -263,6 +263,12 @@ class Renderer:
         check(lib().rt_renderer_last_kernel_ms(self.h, C.byref(ms)))
         return ms.value
 
+    def kernel_times(self, renders_back=0):
+        """(primary_rays_kernel, render_kernel_stream, resolve_kernel) ms of one of the last 32 render calls, by HIP events."""
+        out = (C.c_float * 3)()
+        check(lib().rt_renderer_kernel_times(self.h, renders_back, out))
+        return tuple(out)
+
     def kernel_info(self):
         """{'variant', 'lds_resident', 'workgroup', 'workgroups_per_cu'} the renderer resolved to."""
         out = (C.c_uint32 * 4)()
@@ -292,6 +298,68 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+class MultiRenderer:
+    """Renderer over the N GPUs of one node from ONE process (rt_multi_renderer_*): tile shards, one RCCL gather at frame end."""
+
+    def __init__(self, handle, cfg):
+        self.h, self.cfg = handle, cfg
+
+    @classmethod
+    def MakeRenderer(cls, render_width, render_height, samples_per_pixel, max_depth, cam, world, n_gpus, seed=1984, devices=None, variant=0):
+        cfg = RenderConfig(render_width, render_height, samples_per_pixel, max_depth, seed, 0, 0, 1, variant)
+        devs = (C.c_int32 * n_gpus)(*devices) if devices is not None else None
+        h = C.c_void_p()
+        check(lib().rt_multi_renderer_create(C.byref(cfg), C.byref(cam), C.byref(world), n_gpus, devs, C.byref(h)))
+        return cls(h, cfg)
+
+    def Render(self):
+        check(lib().rt_multi_renderer_render(self.h))
+
+    def DownloadRenderbuffer(self):
+        out = np.zeros((self.cfg.height, self.cfg.width, 4), dtype=np.float32)
+        check(lib().rt_multi_renderer_download(self.h, out, out.size))
+        return out
+
+    def times(self):
+        """(host wall-clock of Render, slowest rank's kernels, exchange + assembly on GPU 0) in ms"""
+        out = (C.c_float * 3)()
+        check(lib().rt_multi_renderer_times(self.h, out))
+        return tuple(out)
+
+    def close(self):
+        if self.h:
+            lib().rt_multi_renderer_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_info(device=0):
+    """rt_device_info: {'compute_units', 'clock_khz', 'memory_mib', 'memory_clock_khz'}"""
+    out = (C.c_uint32 * 4)()
+    check(lib().rt_device_info(device, out))
+    return {"compute_units": out[0], "clock_khz": out[1], "memory_mib": out[2], "memory_clock_khz": out[3]}
+
+
+def shard_layout(width, height, world_size):
+    """rt_shard_layout (host): (tiles_x, n_tiles, n_local_tiles, shard_floats)"""
+    out = (C.c_uint32 * 4)()
+    check(lib().rt_shard_layout(width, height, world_size, out))
+    return tuple(out)
+
+
+def shard_pixel_map(width, height, world_size, rank):
+    """rt_shard_pixel_map (host): global pixel id of every position of rank's shard, 0xffffffff for padding"""
+    n = shard_layout(width, height, world_size)[2] * 64
+    out = np.zeros(n, np.uint32)
+    check(lib().rt_shard_pixel_map(width, height, world_size, rank, out, n))
+    return out
 
 
 # --- device probes -------------------------------------------------------------------------------

@@ -69,12 +69,26 @@ SYMBOLS = [
     "rt_scene_set_world_node_tree", "rt_scene_get_flat", "rt_scene_book1_final", "rt_scene_book2_moving",
     "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
     "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_kernel_info", "rt_renderer_download", "rt_renderer_shard_floats",
-    "rt_renderer_assemble", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
+    "rt_renderer_assemble", "rt_renderer_kernel_times", "rt_multi_renderer_create", "rt_multi_renderer_destroy", "rt_multi_renderer_render",
+    "rt_multi_renderer_download", "rt_multi_renderer_times", "rt_multi_renderer_gpus", "rt_shard_layout", "rt_shard_pixel_map", "rt_device_info", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
     "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_math", "rt_probe_glm", "rt_probe_aabb_misc", "rt_probe_aabb_regular", "rt_probe_boxpair_filtered",
     "rt_selftest_fastdiv", "rt_selftest_fastdiv4", "rt_selftest_fastrcp", "rt_device_count", "rt_version",
 ]
 
 _lib = None
+
+
+def source_hash():
+    """sha256 over the sources librt06.so is built from (csrc/*, include/rt06.h), in name order: stamps the committed
+    rocprofv3 counter summaries so that bench.py can tell whether they describe the library that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile")
+    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "rt06.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def build_native(force=False):
@@ -151,6 +165,17 @@ def lib():
     L.rt_renderer_render_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.rt_renderer_last_kernel_ms.argtypes = [C.c_void_p, P(C.c_float)]
     L.rt_renderer_kernel_info.argtypes = [C.c_void_p, P(C.c_uint32 * 4)]
+    L.rt_renderer_kernel_times.argtypes = [C.c_void_p, C.c_uint32, C.c_float * 3]
+    L.rt_multi_renderer_create.argtypes = [P(RenderConfig), P(Camera), P(WorldFlat), C.c_uint32, C.c_void_p, P(C.c_void_p)]
+    L.rt_multi_renderer_destroy.argtypes = [C.c_void_p]
+    L.rt_multi_renderer_destroy.restype = None
+    L.rt_multi_renderer_render.argtypes = [C.c_void_p]
+    L.rt_multi_renderer_download.argtypes = [C.c_void_p, f32p, C.c_size_t]
+    L.rt_multi_renderer_times.argtypes = [C.c_void_p, C.c_float * 3]
+    L.rt_multi_renderer_gpus.argtypes = [C.c_void_p, P(C.c_uint32)]
+    L.rt_device_info.argtypes = [C.c_int32, C.c_uint32 * 4]
+    L.rt_shard_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32 * 4]
+    L.rt_shard_pixel_map.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_size_t]
     L.rt_renderer_download.argtypes = [C.c_void_p, f32p, C.c_size_t]
     L.rt_renderer_shard_floats.argtypes = [C.c_void_p, P(C.c_size_t)]
     L.rt_renderer_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

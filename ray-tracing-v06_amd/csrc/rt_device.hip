@@ -1,8 +1,13 @@
 // rt_device.hip — HIP kernels (gfx950) and the device half of the C ABI: Renderer + probes.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
 #include <cstdio>
 #include <algorithm>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -39,6 +44,7 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }   // re-allocation (a scene packed twice) must not leak the first buffer
         bytes = n;
         return hipMalloc(&p, n ? n : 1);
     }
@@ -307,6 +313,53 @@ int select_device(int device) {
 }
 }  // namespace
 
+// Pixel ownership: 8x8 tiles in row-major tile order, tile t belongs to rank t % world_size; a rank's shard
+// is tile-major and has the same size on every rank (the last tiles may be padding).
+static TileMap make_tile_map(uint32_t width, uint32_t height, uint32_t rank, uint32_t world_size) {
+    TileMap tm{};
+    tm.width = width; tm.height = height;
+    tm.tiles_x = (width + RT_TILE - 1) / RT_TILE;
+    const uint32_t tiles_y = (height + RT_TILE - 1) / RT_TILE;
+    tm.n_tiles = tm.tiles_x * tiles_y;
+    tm.rank = rank; tm.world_size = world_size;
+    tm.n_local_tiles = (tm.n_tiles + world_size - 1) / world_size;
+    tm.direct = world_size == 1 ? 1u : 0u;
+    return tm;
+}
+
+extern "C" int rt_device_info(int device, uint32_t out[4]) {
+    if (!out) return rt_fail(RT_ERR_INVALID, "rt_device_info: null out");
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    out[0] = (uint32_t)prop.multiProcessorCount;      // compute units
+    out[1] = (uint32_t)prop.clockRate;                 // peak engine clock, kHz
+    out[2] = (uint32_t)(prop.totalGlobalMem >> 20);   // HBM, MiB
+    out[3] = (uint32_t)prop.memoryClockRate;           // kHz
+    return RT_OK;
+}
+
+extern "C" int rt_shard_layout(uint32_t width, uint32_t height, uint32_t world_size, uint32_t out[4]) {
+    if (!out || width == 0 || height == 0 || world_size == 0) return rt_fail(RT_ERR_INVALID, "rt_shard_layout: bad argument");
+    const TileMap tm = make_tile_map(width, height, 0, world_size);
+    out[0] = tm.tiles_x; out[1] = tm.n_tiles; out[2] = tm.n_local_tiles; out[3] = tm.n_local_tiles * RT_TILE * RT_TILE * 4u;
+    return RT_OK;
+}
+
+extern "C" int rt_shard_pixel_map(uint32_t width, uint32_t height, uint32_t world_size, uint32_t rank, uint32_t* out_gid, size_t n) {
+    if (!out_gid || width == 0 || height == 0 || world_size == 0 || rank >= world_size) return rt_fail(RT_ERR_INVALID, "rt_shard_pixel_map: bad argument");
+    const TileMap tm = make_tile_map(width, height, rank, world_size);
+    if (n != (size_t)tm.n_local_tiles * RT_TILE * RT_TILE) return rt_fail(RT_ERR_INVALID, "rt_shard_pixel_map: a shard has %u pixels", tm.n_local_tiles * RT_TILE * RT_TILE);
+    for (uint32_t L = 0; L < (uint32_t)n; L++) {   // the host statement of local_pixel_to_gid (csrc/rt_render_kernels.hpp)
+        const uint32_t tl = L / (RT_TILE * RT_TILE), p = L % (RT_TILE * RT_TILE);
+        const uint32_t gt = tl * world_size + rank;
+        const uint32_t x = (gt % tm.tiles_x) * RT_TILE + (p % RT_TILE), y = (gt / tm.tiles_x) * RT_TILE + (p / RT_TILE);
+        out_gid[L] = (gt < tm.n_tiles && x < width && y < height) ? y * width + x : 0xffffffffu;
+    }
+    return RT_OK;
+}
+
 extern "C" int rt_device_count(int* out) {
     if (!out) return rt_fail(RT_ERR_INVALID, "rt_device_count: null out");
     int n = 0;
@@ -342,6 +395,11 @@ struct rt_renderer {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // per-kernel HIP events of the last RT_TIMES_RING render calls (last pass of each), on the stream the kernels run on:
+    // [0] before primary_rays_kernel, [1] before the streaming kernel, [2] after it, [3] after resolve_kernel
+    static constexpr uint32_t RT_TIMES_RING = 32;
+    hipEvent_t kev[RT_TIMES_RING][4] = {};
+    uint64_t n_renders = 0;
 
     // Pick the kernel variant and size the per-pass sample buffer.
     //   0 = default (the fastest validated variant), 1 = baseline wave-per-pixel kernel,
@@ -357,9 +415,10 @@ struct rt_renderer {
         bool can_stream = scene.has_packed;
         if (can_stream) {
             stream_block = RT_STREAM_BLOCK;
-            if (const char* env = std::getenv("RT06_BLOCK")) {  // occupancy experiments: 512 / 768 / 1024 threads
-                int v = std::atoi(env);
-                if (v == 512 || v == 768 || v == 1024) stream_block = (uint32_t)v;
+            if (const char* env = std::getenv("RT06_BLOCK")) {  // occupancy experiments: 512 / 768 / 1024 threads — instantiated for the
+                int v = std::atoi(env);                         // reference-feature BVH kernel (variant 3) only; every other kernel is 768
+                const bool has_instances = !scene.big && !scene.extended && scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && (cfg.variant == 0 || cfg.variant == 3);
+                if ((v == 512 || v == 768 || v == 1024) && has_instances) stream_block = (uint32_t)v;
             }
             if (scene.big) {  // the per-lane stacks (32-bit entries) and, in what two workgroups per CU leave free, the top of the tree
                 stream_block = RT_STREAM_BLOCK;
@@ -494,6 +553,8 @@ struct rt_renderer {
             p.phase_acc = phase_acc.as<unsigned long long>();
 #endif
             const int pb = 0;
+            hipEvent_t* ke = kev[n_renders % RT_TIMES_RING];
+            HIP_TRY(hipEventRecord(ke[0], st));
             {
                 const size_t n_pass = (size_t)tm.n_local_tiles * RT_TILE * RT_TILE * pass_spp;   // 16-B records per array
                 p.prim_o = primary[pb].as<float4>();
@@ -507,7 +568,9 @@ struct rt_renderer {
             }
 
             void* args[] = {&p};
+            HIP_TRY(hipEventRecord(ke[1], st));
             HIP_TRY(hipLaunchKernel(stream_kernel_ptr(), dim3(grid), dim3(stream_block), args, stream_lds_bytes, st));
+            HIP_TRY(hipEventRecord(ke[2], st));
 #ifdef RT_PHASE_TIMERS
             {
                 static unsigned long long h[32 + 96 * 16];
@@ -530,10 +593,13 @@ struct rt_renderer {
             uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
             resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(ke[3], st));
         }
+        n_renders++;
         return RT_OK;
     }
     ~rt_renderer() {
+        for (auto& q : kev) for (hipEvent_t e : q) if (e) (void)hipEventDestroy(e);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -554,14 +620,8 @@ extern "C" int rt_renderer_create(const rt_render_config* cfg, const rt_camera* 
     r->cam = *cam;
     rc = r->scene.upload(world);
     if (rc != RT_OK) { delete r; return rc; }
+    r->tm = make_tile_map(cfg->width, cfg->height, cfg->rank, cfg->world_size);
     TileMap& tm = r->tm;
-    tm.width = cfg->width; tm.height = cfg->height;
-    tm.tiles_x = (cfg->width + RT_TILE - 1) / RT_TILE;
-    uint32_t tiles_y = (cfg->height + RT_TILE - 1) / RT_TILE;
-    tm.n_tiles = tm.tiles_x * tiles_y;
-    tm.rank = cfg->rank; tm.world_size = cfg->world_size;
-    tm.n_local_tiles = (tm.n_tiles + cfg->world_size - 1) / cfg->world_size;
-    tm.direct = cfg->world_size == 1 ? 1u : 0u;
     r->shard_floats = (size_t)tm.n_local_tiles * RT_TILE * RT_TILE * 4;
     size_t fb_floats = tm.direct ? (size_t)cfg->width * cfg->height * 4 : r->shard_floats;
     hipError_t e = r->fb.alloc(fb_floats * sizeof(float));
@@ -574,6 +634,7 @@ extern "C" int rt_renderer_create(const rt_render_config* cfg, const rt_camera* 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&r->ev0);
     if (e == hipSuccess) e = hipEventCreate(&r->ev1);
+    for (auto& q : r->kev) for (hipEvent_t& ke : q) if (e == hipSuccess) e = hipEventCreate(&ke);
     if (e != hipSuccess) { delete r; return rt_fail(RT_ERR_HIP, "rt_renderer_create: %s", hipGetErrorString(e)); }
     *out = r;
     return RT_OK;
@@ -614,6 +675,19 @@ extern "C" int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms) {
     return RT_OK;
 }
 
+extern "C" int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms[3]) {
+    if (!r || !out_ms) return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_times: null argument");
+    if (r->variant < 2) return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_times: the baseline kernel (variant 1) is one launch; use rt_renderer_last_kernel_ms");
+    if (renders_back >= rt_renderer::RT_TIMES_RING || renders_back >= r->n_renders)
+        return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_times: render %u calls back is not recorded (%llu rendered, ring of %u)", renders_back,
+                       (unsigned long long)r->n_renders, rt_renderer::RT_TIMES_RING);
+    HIP_TRY(hipSetDevice(r->cfg.device));
+    hipEvent_t* ke = r->kev[(r->n_renders - 1 - renders_back) % rt_renderer::RT_TIMES_RING];
+    HIP_TRY(hipEventSynchronize(ke[3]));
+    for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(out_ms + k, ke[k], ke[k + 1]));
+    return RT_OK;
+}
+
 extern "C" int rt_renderer_kernel_info(rt_renderer* r, uint32_t out[4]) {
     if (!r || !out) return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_info: null argument");
     out[0] = r->variant;
@@ -629,6 +703,8 @@ extern "C" int rt_renderer_download(rt_renderer* r, float* host_rgba, size_t n_f
     size_t need = (size_t)r->cfg.width * r->cfg.height * 4;
     if (n_floats != need) return rt_fail(RT_ERR_INVALID, "rt_renderer_download: buffer holds %zu floats, image needs %zu", n_floats, need);
     HIP_TRY(hipSetDevice(r->cfg.device));
+    // the last render may have been launched on a caller's stream (rt_renderer_render_async): its end event orders the copy
+    if (r->timed) HIP_TRY(hipEventSynchronize(r->ev1));
     HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipMemcpy(host_rgba, r->fb.p, need * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
@@ -659,6 +735,182 @@ extern "C" int rt_renderer_assemble(rt_renderer* r, const float* d_gathered, flo
     assemble_kernel<<<(n + 255) / 256, 256, 0, st>>>((const float4*)d_gathered, (float4*)d_image, r->tm,
                                                       (uint32_t)(r->shard_floats / 4));
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU renderer: ONE host process drives the N GPUs of a node (SURVEY.md §5 last row, §8e).  Rank i = device i renders
+// the tiles t with t % N == i into its compact shard; at frame end ONE grouped RCCL exchange moves the shards to device 0
+// over xGMI (every peer has its own link to the root, so the N - 1 transfers run side by side), and assemble_kernel
+// de-interleaves them into the row-major image there.  Nothing else is communicated: the scene is replicated (tens of KB)
+// and the RNG is keyed by global pixel and sample, so the image has the same bits for every N.
+// RCCL is bound at first use (dlopen of librccl.so.1: ncclCommInitAll, ncclGroupStart/End, ncclSend, ncclRecv,
+// ncclCommDestroy, ncclGetErrorString) so that single-GPU callers do not map the 570-MB collective library.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_bind() {
+    if (g_rccl.handle) return RT_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return rt_fail(RT_ERR_HIP, "multi-GPU rendering needs RCCL: %s", dlerror());
+    RcclApi a;
+    a.handle = h;
+#define RT_RCCL_SYM(field, name)                                                                    \
+    a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));                                  \
+    if (!a.field) return rt_fail(RT_ERR_HIP, "librccl.so.1 has no symbol %s", name)
+    RT_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    RT_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RT_RCCL_SYM(GroupStart, "ncclGroupStart");
+    RT_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    RT_RCCL_SYM(Send, "ncclSend");
+    RT_RCCL_SYM(Recv, "ncclRecv");
+    RT_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef RT_RCCL_SYM
+    g_rccl = a;
+    return RT_OK;
+}
+}  // namespace
+
+#define RCCL_TRY(expr)                                                                                                  \
+    do {                                                                                                                \
+        ncclResult_t _r = (expr);                                                                                       \
+        if (_r != ncclSuccess) return rt_fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+    } while (0)
+
+struct rt_multi_renderer {
+    uint32_t width = 0, height = 0;
+    std::vector<int> devices;
+    std::vector<rt_renderer*> parts;     // parts[i]: rank i of N on devices[i]
+    std::vector<ncclComm_t> comms;
+    DevBuf gathered, image;              // on devices[0]: N shards back to back; the assembled row-major frame
+    hipEvent_t ev_rendered = nullptr, ev_done = nullptr;   // on devices[0]'s stream: before the exchange / after the assembly
+    float last_total_ms = 0.0f;
+    bool rendered = false;
+    ~rt_multi_renderer() {
+        for (ncclComm_t c : comms) if (c) (void)g_rccl.CommDestroy(c);
+        for (rt_renderer* r : parts) rt_renderer_destroy(r);
+        if (!devices.empty()) (void)hipSetDevice(devices[0]);
+        if (ev_rendered) (void)hipEventDestroy(ev_rendered);
+        if (ev_done) (void)hipEventDestroy(ev_done);
+    }
+};
+
+extern "C" int rt_multi_renderer_create(const rt_render_config* cfg, const rt_camera* cam, const rt_world_flat* world, uint32_t n_gpus,
+                                        const int32_t* devices, rt_multi_renderer** out) {
+    if (!cfg || !cam || !world || !out) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: null argument");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return rt_fail(RT_ERR_NO_DEVICE, "no HIP device available: the HIP path is required, there is no CPU fallback");
+    if (n_gpus == 0 || (int)n_gpus > n_dev) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: %u GPUs asked for, %d present", n_gpus, n_dev);
+    std::vector<int> devs(n_gpus);
+    for (uint32_t i = 0; i < n_gpus; i++) {
+        devs[i] = devices ? devices[i] : (int)i;
+        if (devs[i] < 0 || devs[i] >= n_dev) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: device %d out of range", devs[i]);
+        for (uint32_t j = 0; j < i; j++)
+            if (devs[j] == devs[i]) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: device %d listed twice (one rank per GPU)", devs[i]);
+    }
+    int rc = rccl_bind();
+    if (rc != RT_OK) return rc;
+    std::unique_ptr<rt_multi_renderer> m(new rt_multi_renderer());
+    m->width = cfg->width; m->height = cfg->height;
+    m->devices = devs;
+    for (uint32_t i = 0; i < n_gpus; i++) {
+        rt_render_config c = *cfg;
+        c.device = devs[i]; c.rank = i; c.world_size = n_gpus;
+        rt_renderer* r = nullptr;
+        rc = rt_renderer_create(&c, cam, world, &r);
+        if (rc != RT_OK) return rc;
+        m->parts.push_back(r);
+    }
+    m->comms.assign(n_gpus, nullptr);
+    RCCL_TRY(g_rccl.CommInitAll(m->comms.data(), (int)n_gpus, devs.data()));
+    HIP_TRY(hipSetDevice(devs[0]));
+    const size_t image_floats = (size_t)cfg->width * cfg->height * 4;
+    HIP_TRY(m->image.alloc(image_floats * sizeof(float)));
+    if (n_gpus > 1) HIP_TRY(m->gathered.alloc(m->parts[0]->shard_floats * n_gpus * sizeof(float)));
+    HIP_TRY(hipEventCreate(&m->ev_rendered));
+    HIP_TRY(hipEventCreate(&m->ev_done));
+    *out = m.release();
+    return RT_OK;
+}
+
+extern "C" void rt_multi_renderer_destroy(rt_multi_renderer* m) { delete m; }
+
+extern "C" int rt_multi_renderer_render(rt_multi_renderer* m) {
+    if (!m) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_render: null renderer");
+    const uint32_t n = (uint32_t)m->parts.size();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; i < n; i++) {   // every GPU renders its tiles; the launches are asynchronous, so the N kernels run side by side
+        int rc = rt_renderer_render_async(m->parts[i], m->parts[i]->stream, nullptr);
+        if (rc != RT_OK) return rc;
+    }
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipEventRecord(m->ev_rendered, m->parts[0]->stream));
+    // the single frame-end exchange: rank i sends its shard to rank 0 (rank 0 to itself), rank 0 receives N shards in rank order.
+    // With one GPU this is the degenerate self-exchange of the whole row-major frame.
+    const size_t count = n > 1 ? m->parts[0]->shard_floats : (size_t)m->width * m->height * 4;
+    float* dst = n > 1 ? m->gathered.as<float>() : m->image.as<float>();
+    RCCL_TRY(g_rccl.GroupStart());
+    for (uint32_t i = 0; i < n; i++) RCCL_TRY(g_rccl.Send(m->parts[i]->fb.p, count, ncclFloat, 0, m->comms[i], m->parts[i]->stream));
+    for (uint32_t i = 0; i < n; i++) RCCL_TRY(g_rccl.Recv(dst + (size_t)i * count, count, ncclFloat, (int)i, m->comms[0], m->parts[0]->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    if (n > 1) {
+        int rc = rt_renderer_assemble(m->parts[0], m->gathered.as<float>(), m->image.as<float>(), m->parts[0]->stream);
+        if (rc != RT_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(m->ev_done, m->parts[0]->stream));
+    for (uint32_t i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        HIP_TRY(hipStreamSynchronize(m->parts[i]->stream));
+    }
+    m->last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    m->rendered = true;
+    return RT_OK;
+}
+
+extern "C" int rt_multi_renderer_download(rt_multi_renderer* m, float* host_rgba, size_t n_floats) {
+    if (!m || !host_rgba) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_download: null argument");
+    const size_t need = (size_t)m->width * m->height * 4;
+    if (n_floats != need) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_download: buffer holds %zu floats, image needs %zu", n_floats, need);
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipStreamSynchronize(m->parts[0]->stream));
+    HIP_TRY(hipMemcpy(host_rgba, m->image.p, need * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_multi_renderer_times(rt_multi_renderer* m, float out_ms[3]) {
+    if (!m || !out_ms) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_times: null argument");
+    if (!m->rendered) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_times: nothing rendered yet");
+    out_ms[0] = m->last_total_ms;
+    float worst = 0.0f;
+    for (rt_renderer* r : m->parts) {
+        float ms = 0.0f;
+        int rc = rt_renderer_last_kernel_ms(r, &ms);
+        if (rc != RT_OK) return rc;
+        worst = std::max(worst, ms);
+    }
+    out_ms[1] = worst;
+    HIP_TRY(hipSetDevice(m->devices[0]));
+    HIP_TRY(hipEventElapsedTime(out_ms + 2, m->ev_rendered, m->ev_done));
+    return RT_OK;
+}
+
+extern "C" int rt_multi_renderer_gpus(const rt_multi_renderer* m, uint32_t* out) {
+    if (!m || !out) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_gpus: null argument");
+    *out = (uint32_t)m->parts.size();
     return RT_OK;
 }
 

@@ -142,13 +142,16 @@ int main(int argc, char** argv) {
             glm::vec3 lookfrom(13, 2, 3), lookat(0, 0, 0), up(0, 1, 0);
             float fov = 30.0f, aspect = width / (float)height;
             auto cam = new MotionBlurCamera(lookfrom, lookat, up, fov, aspect, 0.1f, 1.0f);
-            Renderer renderer = Renderer::MakeRenderer(width, height, spp, depth, cam, scene_ptr->getWorldPtr());
+            // `first_app render W H spp depth out.ppm --gpus N`: tile-shard the frame over N GPUs, one RCCL gather (not in the reference)
+            uint32_t n_gpus = 1;
+            for (int a = 2; a + 1 < argc; a++) if (std::string(argv[a]) == "--gpus") n_gpus = (uint32_t)std::atoi(argv[a + 1]);
+            Renderer renderer = Renderer::MakeRenderer(width, height, spp, depth, cam, scene_ptr->getWorldPtr(), 1984, 0, n_gpus);
             std::vector<glm::vec4> host_output_framebuffer((size_t)width * height);
             renderer.Render();
             renderer.DownloadRenderbuffer(host_output_framebuffer.data());
             std::printf("render %ux%u spp=%u depth=%u kernel_ms=%.3f fnv=%016llx\n", width, height, spp, depth, renderer.LastKernelMs(),
                         (unsigned long long)fnv1a(host_output_framebuffer.data(), host_output_framebuffer.size() * sizeof(glm::vec4)));
-            if (argc > 6) write_renderbuffer(argv[6], width, height, host_output_framebuffer.data());
+            if (argc > 6 && std::string(argv[6]) != "--gpus" && std::string(argv[6]) != "-") write_renderbuffer(argv[6], width, height, host_output_framebuffer.data());
             delete cam;
         }
         delete scene_ptr;

@@ -1,0 +1,89 @@
+"""The multi-GPU renderer behind the C ABI (rt_multi_renderer_*: one host process, N GPUs, one grouped RCCL exchange).
+
+CPU: the C-side shard layout is the one ray-tracing-v06_amd/multigpu.py and the gloo tests use, and the per-rank pixel maps
+partition the frame.  GPU (one-GPU box): the N = 1 communicator (ncclCommInitAll over one device, self send/recv inside a group)
+renders the same bits as the plain renderer, and bad device lists are refused.  N > 1 needs N GPUs: RCCL refuses two ranks on
+one device, so the 8-GPU exchange itself is exercised by the driver's scaling run only; its layout and assembly are covered
+here, by tests/test_dist_gloo.py (gloo, 2 and 3 processes) and by test_tile_sharding_is_gpu_count_invariant (N = 2, 3, 8 on one GPU)."""
+import numpy as np
+import pytest
+
+from _common import config_cameras, config_scene, pkg
+
+
+@pytest.mark.parametrize("W,H,N", [(1200, 800, 8), (1200, 800, 1), (600, 600, 4), (3840, 2160, 8), (203, 117, 3), (7, 5, 2), (64, 8, 16)])
+def test_c_shard_layout_equals_python_tile_layout_and_partitions_the_frame(W, H, N):
+    p = pkg()
+    from ray_tracing_v06_amd import multigpu
+    assert p.api.shard_layout(W, H, N) == multigpu.tile_layout(W, H, N)
+    tiles_x, n_tiles, n_local, shard_floats = p.api.shard_layout(W, H, N)
+    seen = np.zeros(W * H, np.int32)
+    for rank in range(N):
+        gid = p.api.shard_pixel_map(W, H, N, rank)
+        assert len(gid) == n_local * 64 == shard_floats // 4
+        real = gid[gid != 0xFFFFFFFF]
+        np.add.at(seen, real, 1)
+        # independent statement of the mapping: shard position L -> tile L // 64 of this rank -> global tile t = tile * N + rank
+        L = np.nonzero(gid != 0xFFFFFFFF)[0]
+        t = (L // 64) * N + rank
+        x = (t % tiles_x) * 8 + (L % 64) % 8
+        y = (t // tiles_x) * 8 + (L % 64) // 8
+        assert np.array_equal(real, (y * W + x).astype(np.uint32))
+    assert np.all(seen == 1), "every pixel belongs to exactly one rank"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["book1_final", "cornell_box"])
+def test_multi_renderer_with_one_gpu_is_the_plain_renderer(which):
+    """N = 1: a real RCCL communicator and a real (self) exchange of the frame on devices[0]"""
+    p = pkg()
+    W, H, spp, depth = 203, 117, 5, 12
+    scene, cam = config_scene(p, which), config_cameras(p, which, W, H)
+    w = scene.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    r.Render()
+    ref = r.DownloadRenderbuffer()
+    r.close()
+    m = p.MultiRenderer.MakeRenderer(W, H, spp, depth, cam, w, 1)
+    for _ in range(2):   # twice: the communicator and buffers are reused across frames
+        m.Render()
+        img = m.DownloadRenderbuffer()
+        assert img.tobytes() == ref.tobytes()
+    total, kernels, exchange = m.times()
+    assert total > 0 and kernels > 0 and exchange >= 0 and total >= kernels * 0.5
+    m.close()
+
+
+@pytest.mark.gpu
+def test_multi_renderer_refuses_bad_device_lists():
+    p = pkg()
+    scene, cam = config_scene(p, "three_spheres"), config_cameras(p, "three_spheres", 64, 36)
+    w = scene.getWorldPtr()
+    n_dev = p.api.device_count()
+    for n, devs in ((0, None), (n_dev + 1, None), (1, [n_dev]), (1, [-1])):
+        with pytest.raises(p.capi.RtError) as e:
+            p.MultiRenderer.MakeRenderer(64, 36, 1, 4, cam, w, n, devices=devs)
+        assert e.value.code == 1   # RT_ERR_INVALID
+    if n_dev >= 2:
+        with pytest.raises(p.capi.RtError):
+            p.MultiRenderer.MakeRenderer(64, 36, 1, 4, cam, w, 2, devices=[0, 0])
+
+
+@pytest.mark.gpu
+def test_multi_renderer_over_all_gpus_of_the_box_matches_single_gpu():
+    """runs the real N > 1 exchange wherever more than one GPU is visible (skipped on a one-GPU box)"""
+    p = pkg()
+    n_dev = p.api.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device")
+    W, H, spp, depth = 600, 400, 8, 50
+    scene, cam = config_scene(p, "book1_final"), config_cameras(p, "book1_final", W, H)
+    w = scene.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    r.Render()
+    ref = r.DownloadRenderbuffer()
+    r.close()
+    m = p.MultiRenderer.MakeRenderer(W, H, spp, depth, cam, w, min(n_dev, 6))
+    m.Render()
+    assert m.DownloadRenderbuffer().tobytes() == ref.tobytes()
+    m.close()
