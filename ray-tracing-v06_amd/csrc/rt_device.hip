@@ -84,7 +84,8 @@ struct DeviceScene {
     bool has_packed = false;
     uint32_t true_stack = 0;  // traversal-stack bound computed from the tree itself
     bool regular_boxes = false;  // all box coordinates inside the fast-division class
-    bool big = false;            // packed with 32-bit references for the global-memory kernel (does not fit the LDS)
+    bool big = false;            // packed for the global-memory kernel (the image does not fit the LDS): 64-byte nodes, breadth-first
+    bool wide = false;           // ... with 32-bit references (2^14 inner nodes / 2^15 leaf codes or more); otherwise 16-bit like the LDS image
 
     // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 76-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
@@ -93,10 +94,15 @@ struct DeviceScene {
         has_packed = false;
         regular_boxes = false;
         big = want_big;
-        const uint32_t ref_leaf = big ? RT_REF_LEAF_BIG : RT_REF_LEAF, ref_irr = big ? RT_REF_IRR_BIG : RT_REF_IRR;
+        // reference width: 16 bits whenever leaf codes (< 0x7fff) and inner-node indices (< 0x4000, the bit below marks rays outside the
+        // fast-division class) fit — always so for an LDS image, usually so for a BIG one
+        const uint64_t n_codes64 = (uint64_t)w->n_prims * 2u + w->n_quads;
+        const uint32_t n_inner_bound = w->kind == RT_WORLD_LIST ? 0u : w->n_nodes;
+        const bool narrow_fits = n_codes64 < (uint64_t)RT_REF_LEAF - 1u && n_inner_bound < RT_REF_IRR;
+        wide = big && (!narrow_fits || w->kind != RT_WORLD_BVH || std::getenv("RT06_FORCE_WIDE") != nullptr);   // (tests force the 32-bit encoding)
+        const uint32_t ref_leaf = wide ? RT_REF_LEAF_BIG : RT_REF_LEAF, ref_irr = wide ? RT_REF_IRR_BIG : RT_REF_IRR;
         const uint32_t sphere_codes = w->n_prims * 2u;
-        if ((uint64_t)w->n_prims * 2u + w->n_quads >= (big ? 0x7ffffff0ull : (uint64_t)RT_REF_LEAF - 1u) || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // references would not fit
-        if (big && w->kind != RT_WORLD_BVH) return RT_OK;
+        if (n_codes64 >= (wide ? 0x7ffffff0ull : (uint64_t)RT_REF_LEAF - 1u) || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // references would not fit
         if (extended && w->kind == RT_WORLD_NODE_TREE) return RT_OK;  // quads / lights / background: BVH and HittableList worlds
         auto leaf_ref = [&](uint32_t prim) -> uint32_t {  // unified primitive index -> leaf reference
             if (prim >= w->n_prims) return ref_leaf | (sphere_codes + (prim - w->n_prims));
@@ -298,7 +304,7 @@ struct DeviceScene {
         if (rc != RT_OK) return rc;
         const bool fits_lds = has_packed && (size_t)packed.blob_vec4 * 16u + (size_t)RT_STREAM_BLOCK * packed.stack_cap * 2u <= 160u * 1024u;
         const char* force = std::getenv("RT06_FORCE_BIG");  // measurements / tests: take the global-memory path for any BVH world
-        if ((!fits_lds || (force && force[0] == '1')) && w->kind == RT_WORLD_BVH) rc = pack(w, true);
+        if (!fits_lds || (force && force[0] == '1')) rc = pack(w, true);
         return rc;
     }
 };
@@ -422,7 +428,7 @@ struct rt_renderer {
             }
             if (scene.big) {  // the per-lane stacks (32-bit entries) and, in what two workgroups per CU leave free, the top of the tree
                 stream_block = RT_STREAM_BLOCK;
-                const uint32_t stacks = (stream_block * scene.packed.stack_cap * 4u + 63u) & ~63u;
+                const uint32_t stacks = (stream_block * scene.packed.stack_cap * (scene.wide ? 4u : 2u) + 63u) & ~63u;
                 const uint32_t budget = stacks + 4096u <= lds_per_cu / 2u ? lds_per_cu / 2u : lds_per_cu;
                 uint32_t top_bytes = budget > stacks ? budget - stacks : 0u;
                 top_bytes = std::min(top_bytes & ~63u, scene.packed.n_inner * (RT_NODE_DWORDS_BIG * 4u));
@@ -444,7 +450,7 @@ struct rt_renderer {
         if (want >= 3 && scene.dw.kind != RT_WORLD_BVH)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need an RT_WORLD_BVH world (a HittableList / bvh_node world runs on variant 2)");
         if (want >= 2 && !can_stream)
-            return rt_fail(RT_ERR_INVALID, "kernel variant %u cannot take this world (HittableList / bvh_node worlds must fit the 160 KiB LDS)", want);
+            return rt_fail(RT_ERR_INVALID, "kernel variant %u cannot take this world (its references or per-lane stacks do not fit)", want);
         if (want >= 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
@@ -485,11 +491,17 @@ struct rt_renderer {
 
     const void* stream_kernel_ptr() const {
         const bool fast = variant == 3;
-        if (scene.big) {
-            if (scene.textured) return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 2, true>)
-                                            : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 2, true>);
-            return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 1, true>)
-                        : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 1, true>);
+        if (scene.big) {   // records in global memory: <EXACT, FILTER, BLOCK, WORLD, EXT, BIG = true, WIDE>
+#define RT_BIG_KERNEL(exact, world, ext, wide_) reinterpret_cast<const void*>(&render_kernel_stream<exact, false, 768, world, ext, true, wide_>)
+            if (scene.dw.kind == RT_WORLD_LIST) return scene.textured ? RT_BIG_KERNEL(true, RT_WORLD_LIST, 2, true) : RT_BIG_KERNEL(true, RT_WORLD_LIST, 1, true);
+            if (scene.dw.kind == RT_WORLD_NODE_TREE) return RT_BIG_KERNEL(true, RT_WORLD_NODE_TREE, 0, true);
+            if (scene.wide) {
+                if (scene.textured) return fast ? RT_BIG_KERNEL(false, RT_WORLD_BVH, 2, true) : RT_BIG_KERNEL(true, RT_WORLD_BVH, 2, true);
+                return fast ? RT_BIG_KERNEL(false, RT_WORLD_BVH, 1, true) : RT_BIG_KERNEL(true, RT_WORLD_BVH, 1, true);
+            }
+            if (scene.textured) return fast ? RT_BIG_KERNEL(false, RT_WORLD_BVH, 2, false) : RT_BIG_KERNEL(true, RT_WORLD_BVH, 2, false);
+            return fast ? RT_BIG_KERNEL(false, RT_WORLD_BVH, 1, false) : RT_BIG_KERNEL(true, RT_WORLD_BVH, 1, false);
+#undef RT_BIG_KERNEL
         }
         if (scene.dw.kind == RT_WORLD_LIST && scene.extended)
             return scene.textured ? reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST, 2>)

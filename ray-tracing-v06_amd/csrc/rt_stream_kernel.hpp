@@ -209,7 +209,10 @@ __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const
 //        leaf codes >= sphere_codes are quads, emitted radiance is accumulated along the path (the reference's
 //        commented `accum_radiance`), the miss colour may be a constant.  A separate instantiation, so the
 //        reference-feature kernels carry none of it.
-template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false>
+// BIG: the records stay in global memory / L2 (the image does not fit the LDS); WIDE: 32-bit references (a BIG world with 2^14
+//      inner nodes or 2^15 leaf codes or more) — a BIG world whose references fit 16 bits keeps the narrow encoding, which halves
+//      the per-lane stacks and leaves that much more of the LDS for the top of the tree.
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false, bool WIDE = BIG>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -217,11 +220,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     const uint32_t wave = tid >> 6;
 
     // reference encoding and lane status codes (see the header of this file)
-    using ref_t = typename std::conditional<BIG, uint32_t, uint16_t>::type;
-    constexpr uint32_t K_LEAF = BIG ? RT_REF_LEAF_BIG : RT_REF_LEAF, K_IRR = BIG ? RT_REF_IRR_BIG : RT_REF_IRR;
-    constexpr uint32_t K_SHADE = BIG ? 0xfffffffcu : 0xffffu, K_NEED = BIG ? 0xfffffffdu : 0x20000u;
-    constexpr uint32_t K_OFF = BIG ? 0xfffffffeu : 0x30000u, K_START = BIG ? 0xffffffffu : 0x40000u;
-    static_assert(!BIG || WORLD == RT_WORLD_BVH, "BIG scenes are BVH worlds");
+    using ref_t = typename std::conditional<WIDE, uint32_t, uint16_t>::type;
+    constexpr uint32_t K_LEAF = WIDE ? RT_REF_LEAF_BIG : RT_REF_LEAF, K_IRR = WIDE ? RT_REF_IRR_BIG : RT_REF_IRR;
+    constexpr uint32_t K_SHADE = WIDE ? 0xfffffffcu : 0xffffu, K_NEED = WIDE ? 0xfffffffdu : 0x20000u;
+    constexpr uint32_t K_OFF = WIDE ? 0xfffffffeu : 0x30000u, K_START = WIDE ? 0xffffffffu : 0x40000u;
+    static_assert(BIG || !WIDE, "an LDS-resident image always has 16-bit references");
 
     // ---- the scene: staged into the LDS with coalesced 16-B loads, or (BIG) left in global memory / L2 -------------
     const uint4* scene_base;
@@ -317,7 +320,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #ifdef RT_PHASE_TIMERS
     unsigned long long pt_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pt_last_ = __builtin_readcyclecounter();
     uint32_t pc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef RT_TRACE_HIST
     uint32_t tr_steps_ = 0, tr_leafs_ = 0;   // per lane: inner-node steps / leaf tests of the current trace (histogram for tools/sched_model.py)
+#endif
 #define RT_PT(i) do { unsigned long long n_ = __builtin_readcyclecounter(); pt_[i] += n_ - pt_last_; pt_last_ = n_; pc_[i]++; } while (0)
 #else
 #define RT_PT(i)
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         cur = go_right ? right_idx : left_idx;
                         if (!(hl || hr)) RT_POP();
 #endif
-#ifdef RT_PHASE_TIMERS
+#ifdef RT_TRACE_HIST
                         tr_steps_++;
 #endif
                     }
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             uint64_t m_leaf = __ballot(at_leaf);
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < K_LEAF) == 0ull)) {
                 if (at_leaf) {
-#ifdef RT_PHASE_TIMERS
+#ifdef RT_TRACE_HIST
                     tr_leafs_++;
 #endif
                     uint32_t code = cur & (K_LEAF - 1u);   // BVH / tree: prim * 2 + is_moving;  list: unified primitive index
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         bool start_trace = false;  // lanes that got a new ray this round begin their trace in ONE place below
         RT_PT(8);
         if (cur == K_SHADE) {  // sample_world's loop body after the trace (Renderer.cu:149-176)
-#ifdef RT_PHASE_TIMERS
+#if defined(RT_PHASE_TIMERS) && defined(RT_TRACE_HIST)   // the histogram's atomics slow the kernel 40x: its own build flag
             atomicAdd(p.phase_acc + 32 + min(tr_steps_, 95u) * 16u + min(tr_leafs_, 15u), 1ull);
             tr_steps_ = 0; tr_leafs_ = 0;
 #endif

@@ -728,6 +728,77 @@ def test_world_larger_than_the_lds_renders_bit_exact_from_global_memory(p, ext):
         p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, variant=4)
 
 
+def _big_list_or_tree(p, kind, n, seed):
+    """n random spheres as a HittableList (HittableList.cuh) or as a bvh_node tree built pairwise bottom-up (bvh_node.cuh)"""
+    rng = np.random.default_rng(seed)
+    s = p.Scene()
+    mats = [s.Lambertian((0.7, 0.3, 0.3)), s.Metal((0.8, 0.8, 0.7), 0.2), s.Dielectric((1, 1, 1), 1.5), s.Lambertian((0.4, 0.6, 0.4))]
+    refs, xs = [], []
+    for i in range(n):
+        c = ((rng.random(3) * 2 - 1) * np.array([30, 0, 30]) + np.array([0, 0.2 + rng.random() * 3, 0])).astype(np.float32)
+        r = float(0.05 + rng.random() * 0.25)
+        m = mats[int(rng.integers(0, len(mats)))]
+        prim = s.MakeMovingSphere(c, c + np.float32([0, 0.3, 0]), r, m) if i % 7 == 0 else s.MakeSphere(c, r, m)
+        refs.append(s.prim_ref(prim))
+        xs.append(float(c[0]))
+    if kind == "list":
+        s.MakeHittableList()
+        return s
+    order = np.argsort(xs)   # neighbours in x pair up first: a usable tree
+    refs = [refs[i] for i in order]
+    while len(refs) > 1:
+        nxt = [s.bvh_node(refs[i], refs[i + 1]) for i in range(0, len(refs) - 1, 2)]
+        if len(refs) % 2:
+            nxt.append(refs[-1])
+        refs = nxt
+    s.set_world_node_tree(refs[0])
+    return s
+
+
+@pytest.mark.parametrize("kind,n", [("list", 5500), ("tree", 3000)])
+def test_list_and_tree_worlds_larger_than_the_lds_stay_on_the_streaming_kernel(p, kind, n):
+    """A HittableList of 5500 spheres (176 KB of sphere records) and a bvh_node tree of 3000 (228 KB of nodes) exceed the 160 KiB
+    LDS: they now run the global-memory form of the streaming kernel (HittableList.cuh:21-34 / bvh_node.cuh:19-24 order kept)
+    instead of falling back to the wave-per-pixel baseline; framebuffer bit-identical to the oracle's."""
+    s = _big_list_or_tree(p, kind, n, 31)
+    W, H, spp = (48, 32, 2) if kind == "list" else (120, 80, 4)
+    cam = p.DefocusBlurCamera((26, 4, 6), (0, 1, 0), (0, 1, 0), 35.0, W / H, 0.05, 24.0)
+    w = s.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, 12, cam, w)
+    info = r.kernel_info()
+    assert info["variant"] == 2 and not info["lds_resident"], info
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    r.close()
+    ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, 12)
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    base = p.Renderer.MakeRenderer(W, H, spp, 12, cam, w, variant=1)   # the former fallback: same image up to summation order
+    base.Render()
+    assert np.nanmax(np.abs(base.DownloadRenderbuffer() - ref)) < 1e-5
+    base.close()
+
+
+@pytest.mark.parametrize("which", ["three_spheres", "node_tree", "book2_moving"])
+def test_forced_global_memory_path_agrees_for_every_world_kind(p, which, monkeypatch):
+    """RT06_FORCE_BIG=1 on a HittableList, a bvh_node tree and a BVH that would fit the LDS; with RT06_FORCE_WIDE=1 also the 32-bit
+    reference encoding (a BVH whose references fit 16 bits keeps them narrow on the global-memory path)"""
+    W, H, spp = 96, 64, 6
+    s = _node_tree_scene(p) if which == "node_tree" else config_scene(p, which)
+    cam = config_cameras(p, "book2_moving" if which != "three_spheres" else which, W, H)
+    images = []
+    for env in ({}, {"RT06_FORCE_BIG": "1"}, {"RT06_FORCE_BIG": "1", "RT06_FORCE_WIDE": "1"}):
+        for k in ("RT06_FORCE_BIG", "RT06_FORCE_WIDE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr())
+        assert r.kernel_info()["lds_resident"] == (not env)
+        r.Render()
+        images.append(r.DownloadRenderbuffer().tobytes())
+        r.close()
+    assert images[0] == images[1] == images[2]
+
+
 def test_lds_and_global_memory_paths_agree_on_the_book_scene(p, monkeypatch):
     """RT06_FORCE_BIG=1 sends a world that WOULD fit the LDS down the global-memory path: same bits."""
     W, H, spp = 200, 120, 10
