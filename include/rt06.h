@@ -134,8 +134,17 @@ typedef struct rt_world_flat {
     const rt_perlin* perlin;     /* RT_MAT_LAMBERTIAN_NOISE: the world's noise tables, or NULL                            */
     const uint8_t*   image;      /* image_width * image_height * 3 bytes, or NULL                                         */
     uint32_t image_height;
-    uint32_t reserved;
+    uint32_t traversal;          /* RT_WORLD_BVH only: RT_TRAVERSAL_STACK (0, the live path) or RT_TRAVERSAL_QUEUE (1)             */
 } rt_world_flat;                 /* 128 B */
+
+/* How BVH::ClosestIntersection walks the tree (rt_scene_set_traversal).
+ * STACK: the reference's live depth-first walk, near child first (BVH.cu:54-106, `_USE_PRIO_QUEUE false`) — every streaming kernel.
+ * QUEUE: the distance-sorted queue the reference carries but disables (BVH.cu:17-49, :80-86): best-first over the whole frontier,
+ *        with its off-by-one (`distances[head]` written after `head++`, :37-39) FIXED.  Capacity 32 (_PRIO_QUEUE_ELEM_COUNT) is
+ *        checked: an overflow is RT_ERR_STACK at the next synchronising call, never silent.  Runs on the baseline kernel
+ *        (variant 1) and the probes only: on the Book-1 final scene it saves 0.6 % of the box tests and costs 4.8 % more leaf
+ *        tests (measured with the instrumented oracle), so no streaming variant was built for it.                        */
+enum { RT_TRAVERSAL_STACK = 0, RT_TRAVERSAL_QUEUE = 1 };
 
 enum {
     RT_CAM_PINHOLE = 0,  /* PinholeCamera     cu_Cameras.cuh:12-31 */
@@ -190,6 +199,8 @@ int rt_scene_prim_bounds(const rt_scene* s, int32_t prim, float out_min[3], floa
 int rt_scene_add_quad(rt_scene* s, const float Q[3], const float u[3], const float v[3], int32_t mat, int32_t* out_quad);
 /* camera::background of "The Next Week": mode 0 = the reference's sky gradient, 1 = constant colour       */
 int rt_scene_set_background(rt_scene* s, uint32_t mode, const float color[3]);
+/* selects RT_TRAVERSAL_STACK / RT_TRAVERSAL_QUEUE for the BVH world of this scene (see the enum)                 */
+int rt_scene_set_traversal(rt_scene* s, uint32_t mode);
 /* perlin::perlin() of "The Next Week": 256 random unit vectors + three Fisher-Yates permutations, drawn from the
  * build's host stream (rt_host_uniforms, stream id 0x9E81) with this seed                                  */
 int rt_scene_set_perlin(rt_scene* s, uint64_t seed);

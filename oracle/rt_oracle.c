@@ -405,6 +405,55 @@ static int bvh_closest_intersection(const orc_world* w, const ray_t* ray, rec_t*
     return hit_any;
 }
 
+/* BVH::ClosestIntersection with the distance-sorted queue the reference carries but disables (`_USE_PRIO_QUEUE false`,
+ * …/geometry/BVH.cu:17-49 and the `#if _USE_PRIO_QUEUE` branch :80-86): every child box that is hit is enqueued with its entry
+ * distance, the queue is kept sorted (largest distance at the bottom) and the NEAREST entry of the whole frontier is
+ * dequeued next — best-first instead of depth-first.  Culling is still at enqueue time only (the box test's
+ * `tmin < rec.distance`); nothing is re-checked at dequeue.
+ * The reference's enqueue is off by one — it increments `head` BEFORE writing `distances[head]` (BVH.cu:37-39), so the
+ * distance lands one slot above its index and the first comparison reads an unwritten slot.  FIXED here, deliberately
+ * and documented: index and distance are written to the same slot, then the insertion sort runs as written
+ * (swap downwards while the entry above is farther, stop at the first that is not: equal distances keep arrival order
+ * relative to the stop rule `>`).  Capacity 32 = _PRIO_QUEUE_ELEM_COUNT; the reference does not check it, this reports
+ * error 4.  Selected per world (orc_world.traversal == 1): an alternative traversal, NOT the live path — images may
+ * differ from the stack traversal in rounding near-ties, like those of another tree. */
+#define ORC_QUEUE 32
+static int bvh_closest_intersection_queue(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err, rng_t* g) {
+    int32_t indices[ORC_QUEUE];
+    float distances[ORC_QUEUE];
+    int head = 0;
+    const orc_node* nodes = w->nodes;
+    float root_dist;
+    if (!node_box(&nodes[w->root], ray, rec->distance, &root_dist, cnt)) return 0;
+#define ORC_ENQUEUE(idx_, dist_)                                                                  \
+    do {                                                                                          \
+        if (head >= ORC_QUEUE) { *err = 4; return hit_any; }                                      \
+        indices[head] = (idx_); distances[head] = (dist_); head++;                                \
+        for (int i_ = head - 1; i_ >= 1; i_--) {                                                  \
+            if (distances[i_] > distances[i_ - 1]) {                                              \
+                float td_ = distances[i_]; distances[i_] = distances[i_ - 1]; distances[i_ - 1] = td_;   \
+                int32_t ti_ = indices[i_]; indices[i_] = indices[i_ - 1]; indices[i_ - 1] = ti_;  \
+            } else break;                                                                         \
+        }                                                                                         \
+        if ((uint32_t)head > cnt->max_stack) cnt->max_stack = head;                               \
+    } while (0)
+    int hit_any = 0;
+    ORC_ENQUEUE(w->root, root_dist);
+    while (head != 0) {
+        int32_t idx = indices[--head];
+        const orc_node* node = &nodes[idx];
+        if (node->left == -1) {
+            hit_any |= any_prim_closest_intersection(w, node->right, ray, rec, cnt, g);
+            continue;
+        }
+        float left_dist = ORC_MISS_DIST, right_dist = ORC_MISS_DIST;
+        if (node_box(&nodes[node->left], ray, rec->distance, &left_dist, cnt)) ORC_ENQUEUE(node->left, left_dist);
+        if (node_box(&nodes[node->right], ray, rec->distance, &right_dist, cnt)) ORC_ENQUEUE(node->right, right_dist);
+    }
+#undef ORC_ENQUEUE
+    return hit_any;
+}
+
 /* HittableList::ClosestIntersection, …/geometry/HittableList.cuh:21-34 */
 static int list_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, rng_t* g) {
     float d;
@@ -433,7 +482,7 @@ static int tree_closest_intersection(const orc_world* w, int32_t ref, const ray_
 static inline int world_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err, rng_t* g) {
     cnt->rays++;
     switch (w->kind) {
-    case 0: return bvh_closest_intersection(w, ray, rec, cnt, err, g);
+    case 0: return w->traversal == 1u ? bvh_closest_intersection_queue(w, ray, rec, cnt, err, g) : bvh_closest_intersection(w, ray, rec, cnt, err, g);
     case 1: return list_closest_intersection(w, ray, rec, cnt, g);
     default: return tree_closest_intersection(w, w->root, ray, rec, cnt, 0, err, g);
     }

@@ -196,6 +196,11 @@ class Scene:
         check(lib().rt_scene_set_world_node_tree(self.h, root_ref))
         return self
 
+    def set_traversal(self, mode):
+        """0 = the live depth-first stack (BVH.cu:54-106), 1 = the reference's disabled distance-sorted queue (BVH.cu:17-49), fixed"""
+        check(lib().rt_scene_set_traversal(self.h, mode))
+        return self
+
     # --- flat view ---
     def getWorldPtr(self):
         w = WorldFlat()

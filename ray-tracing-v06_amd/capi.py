@@ -39,7 +39,7 @@ class WorldFlat(C.Structure):
                 ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p),
                 ("quads", C.c_void_p), ("n_quads", C.c_uint32), ("background", C.c_uint32),
                 ("background_color", vec3), ("image_width", C.c_uint32),
-                ("perlin", C.c_void_p), ("image", C.c_void_p), ("image_height", C.c_uint32), ("reserved", C.c_uint32)]
+                ("perlin", C.c_void_p), ("image", C.c_void_p), ("image_height", C.c_uint32), ("traversal", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -70,7 +70,7 @@ SYMBOLS = [
     "rt_scene_three_spheres", "rt_host_uniforms", "rt_renderer_create", "rt_renderer_destroy", "rt_renderer_render",
     "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_kernel_info", "rt_renderer_download", "rt_renderer_shard_floats",
     "rt_renderer_assemble", "rt_renderer_kernel_times", "rt_multi_renderer_create", "rt_multi_renderer_destroy", "rt_multi_renderer_render",
-    "rt_multi_renderer_download", "rt_multi_renderer_times", "rt_multi_renderer_gpus", "rt_shard_layout", "rt_shard_pixel_map", "rt_device_info", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
+    "rt_multi_renderer_download", "rt_multi_renderer_times", "rt_multi_renderer_gpus", "rt_shard_layout", "rt_shard_pixel_map", "rt_device_info", "rt_scene_set_traversal", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
     "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_math", "rt_probe_glm", "rt_probe_aabb_misc", "rt_probe_aabb_regular", "rt_probe_boxpair_filtered",
     "rt_selftest_fastdiv", "rt_selftest_fastdiv4", "rt_selftest_fastrcp", "rt_device_count", "rt_version",
 ]
@@ -174,6 +174,7 @@ def lib():
     L.rt_multi_renderer_times.argtypes = [C.c_void_p, C.c_float * 3]
     L.rt_multi_renderer_gpus.argtypes = [C.c_void_p, P(C.c_uint32)]
     L.rt_device_info.argtypes = [C.c_int32, C.c_uint32 * 4]
+    L.rt_scene_set_traversal.argtypes = [C.c_void_p, C.c_uint32]
     L.rt_shard_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32 * 4]
     L.rt_shard_pixel_map.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, C.c_size_t]
     L.rt_renderer_download.argtypes = [C.c_void_p, f32p, C.c_size_t]

@@ -76,7 +76,7 @@ static void write_wide_node(uint4* blob, bool big, uint32_t index, const float l
 }
 
 struct DeviceScene {
-    DevBuf nodes, prims, mats, blob, quads, perlin, image;
+    DevBuf nodes, prims, mats, blob, quads, perlin, image, error_flag;
     bool extended = false;  // quads, an emissive material or a constant background: beyond the reference's feature set
     bool textured = false;  // a Perlin or image material: the EXT = 2 kernels
     DeviceWorld dw{};
@@ -217,6 +217,8 @@ struct DeviceScene {
         if ((w->n_prims == 0 || !w->prims) && (w->n_quads == 0 || !w->quads)) return rt_fail(RT_ERR_INVALID, "world has no primitives");
         if ((w->n_prims && !w->prims) || (w->n_quads && !w->quads)) return rt_fail(RT_ERR_INVALID, "world primitive array is null");
         if (w->background > 1) return rt_fail(RT_ERR_INVALID, "unknown background mode %u", w->background);
+        if (w->traversal > RT_TRAVERSAL_QUEUE || (w->traversal != RT_TRAVERSAL_STACK && w->kind != RT_WORLD_BVH))
+            return rt_fail(RT_ERR_INVALID, "traversal mode %u: the distance-sorted queue belongs to RT_WORLD_BVH worlds", w->traversal);
         if (w->n_quads && w->kind == RT_WORLD_NODE_TREE) return rt_fail(RT_ERR_INVALID, "bvh_node trees take spheres only");
         const uint32_t n_all = w->n_prims + w->n_quads;
         if (w->n_materials == 0 || !w->materials) return rt_fail(RT_ERR_INVALID, "world has no materials");
@@ -298,8 +300,13 @@ struct DeviceScene {
         dw.perlin = w->perlin ? perlin.as<rt_perlin>() : nullptr;
         dw.image = w->image ? image.as<uint8_t>() : nullptr;
         dw.image_w = w->image_width; dw.image_h = w->image_height;
+        dw.traversal = w->traversal;
+        HIP_TRY(error_flag.alloc(4));
+        HIP_TRY(hipMemset(error_flag.p, 0, 4));
+        dw.error_flag = error_flag.as<uint32_t>();
         // 16-bit references and an LDS-resident image when that fits (2 x 768-thread workgroups per CU want <= 80 KiB each,
         // one workgroup may take all 160 KiB); otherwise 32-bit references and the records stay in global memory / L2
+        if (w->traversal == RT_TRAVERSAL_QUEUE) { has_packed = false; return RT_OK; }   // baseline kernel and probes only (rt06.h)
         int rc = pack(w, false);
         if (rc != RT_OK) return rc;
         const bool fits_lds = has_packed && (size_t)packed.blob_vec4 * 16u + (size_t)RT_STREAM_BLOCK * packed.stack_cap * 2u <= 160u * 1024u;
@@ -308,6 +315,18 @@ struct DeviceScene {
         return rc;
     }
 };
+
+// RT_TRAVERSAL_QUEUE: has a lane overflowed the 32-entry queue?  Called after a synchronisation.
+int check_traversal_overflow(DeviceScene& sc) {
+    if (sc.dw.traversal != RT_TRAVERSAL_QUEUE) return RT_OK;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, sc.error_flag.p, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(sc.error_flag.p, 0, 4));
+        return rt_fail(RT_ERR_STACK, "the distance-sorted traversal queue overflowed its %d entries (_PRIO_QUEUE_ELEM_COUNT, BVH.cu:17): the results are incomplete", RT_MAX_STACK);
+    }
+    return RT_OK;
+}
 
 int select_device(int device) {
     int n = 0;
@@ -675,7 +694,7 @@ extern "C" int rt_renderer_render(rt_renderer* r) {
     int rc = rt_renderer_render_async(r, r->stream, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
-    return RT_OK;
+    return check_traversal_overflow(r->scene);
 }
 
 extern "C" int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms) {
@@ -719,7 +738,7 @@ extern "C" int rt_renderer_download(rt_renderer* r, float* host_rgba, size_t n_f
     if (r->timed) HIP_TRY(hipEventSynchronize(r->ev1));
     HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipMemcpy(host_rgba, r->fb.p, need * sizeof(float), hipMemcpyDeviceToHost));
-    return RT_OK;
+    return check_traversal_overflow(r->scene);
 }
 
 extern "C" int rt_renderer_shard_floats(const rt_renderer* r, size_t* out) {
@@ -1079,7 +1098,7 @@ extern "C" int rt_probe_trace(int device, const rt_world_flat* world, size_t n, 
     probe_trace_kernel<<<PROBE_GRID(n)>>>(sc.dw, n, r.as<float>(), h.as<int32_t>(), t.as<float>(), p.as<int32_t>(), nn.as<float>());
     FINISH();
     DOWN(out_hit, h, n * 4); DOWN(out_t, t, n * 4); DOWN(out_prim, p, n * 4); DOWN(out_normal, nn, n * 12);
-    return RT_OK;
+    return check_traversal_overflow(sc);
 }
 extern "C" int rt_probe_scatter(int device, uint64_t seed, size_t n, const rt_material* mats, const float* rays, const float* dist,
                                 const float* normals, const uint32_t* keys, int32_t* out_scattered, float* out_rays, float* out_atten,
@@ -1134,7 +1153,7 @@ extern "C" int rt_probe_radiance(const rt_render_config* cfg, const rt_camera* c
     probe_radiance_kernel<<<PROBE_GRID(n)>>>(sc.dw, *cam, cfg->width, cfg->height, cfg->max_depth, cfg->seed, n, k.as<uint32_t>(), o.as<float>());
     FINISH();
     DOWN(out_radiance, o, n * 12);
-    return RT_OK;
+    return check_traversal_overflow(sc);
 }
 extern "C" int rt_probe_sphere_index(int device, const rt_camera* cam, uint32_t width, uint32_t height, size_t n_spheres,
                                      const float* spheres, int32_t* out_index) {

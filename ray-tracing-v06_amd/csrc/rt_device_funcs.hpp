@@ -26,6 +26,8 @@ struct DeviceWorld {
     const rt_perlin* perlin;   // RT_MAT_LAMBERTIAN_NOISE tables (global memory), or null
     const uint8_t* image;      // RT_MAT_LAMBERTIAN_IMAGE RGB8 image, or null
     uint32_t image_w, image_h;
+    uint32_t traversal;        // RT_TRAVERSAL_STACK / RT_TRAVERSAL_QUEUE (BVH worlds)
+    uint32_t* error_flag;      // set to 1 when the distance-sorted queue overflows its 32 entries (checked by the host, never silent)
 };
 
 // RayPayload (ray_data.cuh:33-40) with Sphere::TraceRecord (SphereHittable.cuh:38-41) unpacked
@@ -178,6 +180,45 @@ __device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray&
     return hit_any;
 }
 
+// BVH::ClosestIntersection with the reference's disabled distance-sorted queue (BVH.cu:17-49 and the `#if _USE_PRIO_QUEUE`
+// branch :80-86): each hit child box is enqueued with its entry distance, the queue stays sorted with the nearest entry on
+// top, the nearest entry of the whole frontier is dequeued next.  The reference's enqueue writes `distances[head]` AFTER
+// `head++` (:37-39: index and distance end up in different slots); fixed here and in the oracle — same slot, then the
+// insertion sort as written.  Capacity _PRIO_QUEUE_ELEM_COUNT = 32, checked (the reference does not): overflow raises
+// *w.error_flag and ends the walk.  Baseline kernel and probes only (see RT_TRAVERSAL_QUEUE in rt06.h).
+__device__ inline bool bvh_closest_intersection_queue(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
+    int32_t indices[RT_MAX_STACK];
+    float distances[RT_MAX_STACK];
+    int head = 0;
+    float root_dist;
+    if (!node_box(w.nodes[w.root], ray, rec.distance, root_dist)) return false;
+    bool hit_any = false;
+    auto enqueue = [&](int32_t idx, float dist) -> bool {
+        if (head >= RT_MAX_STACK) { *w.error_flag = 1u; return false; }
+        indices[head] = idx; distances[head] = dist; head++;
+        for (int i = head - 1; i >= 1; i--) {
+            if (distances[i] > distances[i - 1]) {
+                float td = distances[i]; distances[i] = distances[i - 1]; distances[i - 1] = td;
+                int32_t ti = indices[i]; indices[i] = indices[i - 1]; indices[i - 1] = ti;
+            } else break;
+        }
+        return true;
+    };
+    enqueue(w.root, root_dist);
+    while (head != 0) {
+        const int32_t idx = indices[--head];
+        const rt_bvh_node& node = w.nodes[idx];
+        if (node.left == -1) {
+            hit_any |= any_prim_closest_intersection(w, node.right, ray, rec, rng);
+            continue;
+        }
+        float left_dist = RT_MISS_DIST, right_dist = RT_MISS_DIST;
+        if (node_box(w.nodes[node.left], ray, rec.distance, left_dist) && !enqueue(node.left, left_dist)) return hit_any;
+        if (node_box(w.nodes[node.right], ray, rec.distance, right_dist) && !enqueue(node.right, right_dist)) return hit_any;
+    }
+    return hit_any;
+}
+
 // HittableList::ClosestIntersection, rt_engine/geometry/HittableList.cuh:21-34
 __device__ inline bool list_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
     float d;
@@ -214,7 +255,7 @@ __device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray
 
 // rng: drawn from by constant media only (one uniform per test that enters the boundary)
 __device__ inline bool world_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
-    if (w.kind == RT_WORLD_BVH) return bvh_closest_intersection(w, ray, rec, rng);
+    if (w.kind == RT_WORLD_BVH) return w.traversal == RT_TRAVERSAL_QUEUE ? bvh_closest_intersection_queue(w, ray, rec, rng) : bvh_closest_intersection(w, ray, rec, rng);
     if (w.kind == RT_WORLD_LIST) return list_closest_intersection(w, ray, rec, rng);
     return tree_closest_intersection(w, ray, rec, rng);
 }

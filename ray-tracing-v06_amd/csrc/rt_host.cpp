@@ -138,6 +138,7 @@ struct rt_scene {
     std::vector<rt_quad> quads;
     uint32_t background = 0;
     float background_color[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t traversal = RT_TRAVERSAL_STACK;
     std::vector<rt_material> mats;
     std::vector<rt_perlin> perlin;        // 0 or 1 table set (RT_MAT_LAMBERTIAN_NOISE)
     std::vector<uint8_t> image;           // RGB8 (RT_MAT_LAMBERTIAN_IMAGE)
@@ -238,6 +239,13 @@ extern "C" int rt_scene_set_background(rt_scene* s, uint32_t mode, const float c
     if (mode > 1) return rt_fail(RT_ERR_INVALID, "rt_scene_set_background: unknown mode %u", mode);
     s->background = mode;
     if (color) st3(s->background_color, ld3(color));
+    return RT_OK;
+}
+
+extern "C" int rt_scene_set_traversal(rt_scene* s, uint32_t mode) {
+    if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_traversal: null scene");
+    if (mode > RT_TRAVERSAL_QUEUE) return rt_fail(RT_ERR_INVALID, "rt_scene_set_traversal: unknown mode %u", mode);
+    s->traversal = mode;
     return RT_OK;
 }
 
@@ -470,6 +478,7 @@ extern "C" int rt_scene_get_flat(const rt_scene* s, rt_world_flat* out) {
     out->image = s->image.empty() ? nullptr : s->image.data();
     out->image_width = s->image_w;
     out->image_height = s->image_h;
+    out->traversal = s->kind == RT_WORLD_BVH ? s->traversal : (uint32_t)RT_TRAVERSAL_STACK;
     return RT_OK;
 }
 

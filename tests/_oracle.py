@@ -35,7 +35,7 @@ class World(C.Structure):
                 ("nodes", C.c_void_p), ("prims", C.c_void_p), ("materials", C.c_void_p),
                 ("quads", C.c_void_p), ("n_quads", C.c_uint32), ("background", C.c_uint32),
                 ("background_color", C.c_float * 3), ("image_width", C.c_uint32),
-                ("perlin", C.c_void_p), ("image", C.c_void_p), ("image_height", C.c_uint32), ("reserved", C.c_uint32)]
+                ("perlin", C.c_void_p), ("image", C.c_void_p), ("image_height", C.c_uint32), ("traversal", C.c_uint32)]
 
 
 class Camera(C.Structure):
