@@ -90,8 +90,8 @@ enum {
                                     * material is a constant_medium bounded by it; albedo = colour, param = density          */
     RT_MAT_LAMBERTIAN_NOISE = 6,   /* lambertian(noise_texture(scale)) of "The Next Week" (not in the reference): colour =
                                     * albedo * (1 + sin(param * p.z + 10 * turb(p, 7))) over the world's Perlin tables        */
-    RT_MAT_LAMBERTIAN_IMAGE = 7    /* lambertian(image_texture) of "The Next Week" on a sphere: colour = the world's RGB8
-                                    * image at the sphere's (u, v)                                                             */
+    RT_MAT_LAMBERTIAN_IMAGE = 7    /* lambertian(image_texture) of "The Next Week": colour = the world's RGB8 image at (u, v) — on a sphere
+                                    * sphere::get_sphere_uv of the normal, on a quad the planar coordinates (alpha, beta) of quad::hit   */
 };
 typedef struct rt_material {
     float    albedo[3];

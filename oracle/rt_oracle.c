@@ -542,12 +542,23 @@ static float perlin_turb(const orc_perlin* t, v3 p, int depth) {
 static v3 noise_value(const orc_perlin* t, v3 albedo, float scale, v3 p) {
     return muls(albedo, 1.0f + m_sinf(scale * p.z + 10.0f * perlin_turb(t, p, 7)));
 }
+/* image_texture::value(u, v) of "The Next Week": clamp, flip v, nearest texel, 1/255 */
+static v3 image_texel(const uint8_t* image, uint32_t width, uint32_t height, float u, float v);
 static v3 image_value(const uint8_t* image, uint32_t width, uint32_t height, v3 n) {
     float cy = -n.y;
     cy = cy < -1.0f ? -1.0f : (cy > 1.0f ? 1.0f : cy);
     float theta = m_acosf(cy);
     float phi = m_atan2f(-n.z, n.x) + 0x1.921fb6p+1f;
-    float u = phi / 0x1.921fb6p+2f, v = theta / 0x1.921fb6p+1f;
+    return image_texel(image, width, height, phi / 0x1.921fb6p+2f, theta / 0x1.921fb6p+1f);
+}
+/* on a quad the texture coordinates are the planar coordinates of the hit, (alpha, beta) of quad::hit, recomputed from the hit point */
+static v3 image_value_quad(const uint8_t* image, uint32_t width, uint32_t height, const orc_quad* q, v3 hit_p) {
+    v3 planar = sub(hit_p, ld3(q->Q));
+    float alpha = dot(ld3(q->w), cross(planar, ld3(q->v)));
+    float beta = dot(ld3(q->w), cross(ld3(q->u), planar));
+    return image_texel(image, width, height, alpha, beta);
+}
+static v3 image_texel(const uint8_t* image, uint32_t width, uint32_t height, float u, float v) {
     u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
     v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
     v = 1.0f - v;
@@ -578,6 +589,8 @@ static int material_scatter(const orc_material* m, const ray_t* in_ray, const re
         if (m->type == 0) *attenuation = ld3(m->albedo);
         else if (m->type == 3) *attenuation = checker_value(m, ray_at(in_ray, rec->distance));
         else if (m->type == 6) *attenuation = noise_value(w->perlin, ld3(m->albedo), m->param, ray_at(in_ray, rec->distance));
+        else if (rec->prim >= 0 && (uint32_t)rec->prim >= w->n_prims)
+            *attenuation = image_value_quad(w->image, w->image_width, w->image_height, &w->quads[(uint32_t)rec->prim - w->n_prims], ray_at(in_ray, rec->distance));
         else *attenuation = image_value(w->image, w->image_width, w->image_height, normal);
         return 1;
     }

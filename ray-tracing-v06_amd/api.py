@@ -125,7 +125,7 @@ class Scene:
         return self
 
     def ImageTexture(self):
-        """lambertian(image_texture) of "The Next Week" on spheres (extension); needs set_image()."""
+        """lambertian(image_texture) of "The Next Week" (extension) on spheres (u, v from the normal) and quads (u, v = the planar coordinates of the hit); needs set_image()."""
         return self.add_material(capi.MAT_LAMBERTIAN_IMAGE, (1, 1, 1))
 
     def MakeBox(self, a, b, mat, rotate_y=0.0, translate=(0, 0, 0)):

@@ -230,7 +230,6 @@ struct DeviceScene {
         for (uint32_t i = 0; i < w->n_quads; i++) {
             if (w->quads[i].mat >= w->n_materials) return rt_fail(RT_ERR_INVALID, "quad %u: material index out of range", i);
             if (w->materials[w->quads[i].mat].type == RT_MAT_ISOTROPIC) return rt_fail(RT_ERR_INVALID, "quad %u: a constant medium is bounded by a sphere (RT_MAT_ISOTROPIC on a quad)", i);
-            if (w->materials[w->quads[i].mat].type == RT_MAT_LAMBERTIAN_IMAGE) return rt_fail(RT_ERR_INVALID, "quad %u: the image texture maps onto spheres only", i);
         }
         extended = w->n_quads != 0 || w->background != 0;
         textured = false;

@@ -316,12 +316,23 @@ RT_HD f3 noise_value(const rt_perlin* t, f3 albedo, float scale, f3 p) {
     return albedo * (1.0f + rt_sinf(scale * p.z + 10.0f * perlin_turb(t, p, 7)));
 }
 // sphere::get_sphere_uv + image_texture::value of "The Next Week" (extension): n = outward unit normal of the sphere
+RT_HD f3 image_texel(const uint8_t* image, uint32_t width, uint32_t height, float u, float v);
 RT_HD f3 image_value(const uint8_t* image, uint32_t width, uint32_t height, f3 n) {
     float cy = -n.y;
     cy = cy < -1.0f ? -1.0f : (cy > 1.0f ? 1.0f : cy);   // the normal is unit only up to rounding
     float theta = rt_acosf(cy);
     float phi = rt_atan2f(-n.z, n.x) + 0x1.921fb6p+1f;
-    float u = phi / 0x1.921fb6p+2f, v = theta / 0x1.921fb6p+1f;
+    return image_texel(image, width, height, phi / 0x1.921fb6p+2f, theta / 0x1.921fb6p+1f);
+}
+// on a quad the texture coordinates are the planar coordinates (alpha, beta) of quad::hit, recomputed from the hit point
+RT_HD f3 image_value_quad(const uint8_t* image, uint32_t width, uint32_t height, f3 Q, f3 u, f3 v, f3 w, f3 hit_p) {
+    f3 planar = hit_p - Q;
+    float alpha = dot(w, cross(planar, v));
+    float beta = dot(w, cross(u, planar));
+    return image_texel(image, width, height, alpha, beta);
+}
+// image_texture::value(u, v) of "The Next Week": clamp, flip v to image coordinates, nearest texel, 1/255
+RT_HD f3 image_texel(const uint8_t* image, uint32_t width, uint32_t height, float u, float v) {
     u = u < 0.0f ? 0.0f : (u > 1.0f ? 1.0f : u);
     v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
     v = 1.0f - v;   // flip to image coordinates
@@ -348,7 +359,11 @@ RT_HD bool material_scatter(const rt_material& m, const Ray& in_ray, const HitRe
         if (m.type == RT_MAT_LAMBERTIAN) attenuation = albedo;
         else if (m.type == RT_MAT_LAMBERTIAN_CHECKER) attenuation = checker_value(albedo, albedo2, m.param, ray_at(in_ray, rec.distance));
         else if (m.type == RT_MAT_LAMBERTIAN_NOISE) attenuation = noise_value(w->perlin, albedo, m.param, ray_at(in_ray, rec.distance));
-        else attenuation = image_value(w->image, w->image_w, w->image_h, normal);
+        else if (rec.prim >= 0 && (uint32_t)rec.prim >= w->n_prims) {
+            const rt_quad& q = w->quads[(uint32_t)rec.prim - w->n_prims];
+            attenuation = image_value_quad(w->image, w->image_w, w->image_h, mk3(q.Q[0], q.Q[1], q.Q[2]), mk3(q.u[0], q.u[1], q.u[2]), mk3(q.v[0], q.v[1], q.v[2]),
+                                           mk3(q.w[0], q.w[1], q.w[2]), ray_at(in_ray, rec.distance));
+        } else attenuation = image_value(w->image, w->image_w, w->image_h, normal);
         return true;
     }
     if (m.type == RT_MAT_ISOTROPIC) {  // isotropic phase function of "The Next Week": a uniformly random direction, always scatters

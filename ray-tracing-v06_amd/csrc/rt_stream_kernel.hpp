@@ -631,7 +631,16 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                             albedo = checker_value(albedo, mk3(mg.albedo2[0], mg.albedo2[1], mg.albedo2[2]), mparam, hit_p);
                         }
                         if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_NOISE) albedo = noise_value(p.scene.perlin, albedo, mparam, hit_p);
-                        if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_IMAGE) albedo = image_value(p.scene.image, p.scene.image_w, p.scene.image_h, normal);
+                        if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_IMAGE) {
+                            if ((uint32_t)rec_code >= p.scene.sphere_codes) {   // on a quad: (u, v) = the planar coordinates of the hit
+                                const float4* qd = quads + ((uint32_t)rec_code - p.scene.sphere_codes) * 5u;
+                                const float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a4 = qd[4];
+                                albedo = image_value_quad(p.scene.image, p.scene.image_w, p.scene.image_h, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z),
+                                                          mk3(a2.x, a2.y, a2.z), mk3(a4.x, a4.y, a4.z), hit_p);
+                            } else {
+                                albedo = image_value(p.scene.image, p.scene.image_w, p.scene.image_h, normal);
+                            }
+                        }
                     }
                 }
                 RT_PT(13);

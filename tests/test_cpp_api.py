@@ -136,3 +136,19 @@ def test_header_is_plain_c_and_the_library_links_from_c():
     build_app()
     out = subprocess.check_output([os.path.join(ROOT, "tests", "cpp", "abi_c_check")], text=True)
     assert "C ABI ok" in out
+
+
+REF_GLM = "/root/reference/Libraries/include"
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF_GLM, "glm")), reason="build container only: needs the reference's vendored GLM (absent on the GPU box)")
+def test_cpp_api_compiles_against_the_references_own_glm_and_flattens_to_the_same_world(tmp_path):
+    """INTEGRATION.md §2 tells a maintainer to build with -DRT06_USE_GLM so that glm::vec3 IS the reference's vendored GLM 0.9.9.7:
+    the FirstApp caller must compile that way and build byte-identical flat arrays."""
+    build_app()
+    exe = str(tmp_path / "first_app_glm")
+    libdir = os.path.join(ROOT, "ray-tracing-v06_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wno-volatile", "-Wno-deprecated-volatile", "-DRT06_USE_GLM", "-DGLM_ENABLE_EXPERIMENTAL",
+                           f"-I{REF_GLM}", f"-I{os.path.join(ROOT, 'include')}", "-o", exe, os.path.join(ROOT, "tests", "cpp", "first_app.cpp"),
+                           f"-L{libdir}", "-lrt06", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.check_output([exe, "flatten"], text=True) == subprocess.check_output([APP, "flatten"], text=True)

@@ -300,12 +300,32 @@ def test_textured_materials_need_their_tables(p):
     s2.BuildBVH_TopDown()
     with pytest.raises(p.capi.RtError, match="image"):
         p.Renderer.MakeRenderer(16, 16, 1, 5, cam, s2.getWorldPtr())
-    s3 = p.Scene()
-    s3.set_image(_test_image())
-    s3.MakeQuad((0, 0, 0), (1, 0, 0), (0, 1, 0), s3.ImageTexture())
-    s3.BuildBVH_TopDown()
-    with pytest.raises(p.capi.RtError, match="spheres only"):
-        p.Renderer.MakeRenderer(16, 16, 1, 5, cam, s3.getWorldPtr())
+
+
+@pytest.mark.parametrize("world", ["bvh", "list"])
+def test_image_texture_on_quads_renders_bit_exact(p, world):
+    """image_texture on a quad: (u, v) are the planar coordinates (alpha, beta) of quad::hit ("The Next Week"), row 0 of the image at
+    v = 1.  A picture on a wall, a textured floor and a tilted panel, next to an image-textured sphere; BVH and HittableList worlds,
+    every kernel variant, against the oracle."""
+    s = p.Scene()
+    s.set_image(_test_image())
+    pic = s.ImageTexture()
+    s.MakeQuad((-3, 0, -2), (6, 0, 0), (0, 4, 0), pic)                 # wall
+    s.MakeQuad((-4, 0, 4), (8, 0, 0), (0, 0, -6), pic)                # floor
+    s.MakeQuad((2.5, 0.2, 1.5), (1.5, 0.3, 0.8), (-0.4, 1.6, 0.3), pic)   # tilted panel
+    s.MakeSphere((-2, 1, 1.5), 1.0, pic)
+    s.MakeSphere((0.5, 0.6, 2.5), 0.6, s.Metal((0.9, 0.9, 0.9), 0.0))
+    s.set_background((0.6, 0.7, 0.9))
+    (s.BuildBVH_TopDown if world == "bvh" else s.MakeHittableList)()
+    W, H, spp = 150, 100, 10
+    cam = p.PinholeCamera((1, 3, 9), (0, 1.2, 0), (0, 1, 0), 40.0, W / H)
+    for variant in (0, 1, 2):
+        img, ref = _render_both(p, s, cam, W, H, spp, variant=variant)
+        if variant == 1:
+            assert np.nanmax(np.abs(img - ref)) <= TOL_MEASURED
+        else:
+            assert bits_equal(img, ref), f"variant {variant}: " + mismatch_report(img, ref)
+    assert ref[..., 0].std() > 0.05 and ref[..., 2].std() > 0.05      # the picture is visible
 
 
 def test_book2_final_scene_renders_bit_exact(p):

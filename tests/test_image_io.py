@@ -3,6 +3,7 @@ import struct
 import zlib
 
 import numpy as np
+import pytest
 
 from _common import pkg
 
@@ -42,3 +43,32 @@ def test_png_and_ppm_follow_the_reference_conversion(tmp_path):
     image_io.write_ppm(str(tmp_path / "a.ppm"), fb)
     data = open(tmp_path / "a.ppm", "rb").read()
     assert data.startswith(b"P6\n7 5\n255\n") and data[len(b"P6\n7 5\n255\n"):] == exp.tobytes()
+
+
+def test_jpeg_q95_is_a_valid_baseline_file_close_to_the_source(tmp_path):
+    """the format the reference app writes (stbi_write_jpg quality 95, FirstApp.cpp:120): decoded by an independent decoder (Pillow) the
+    picture must be the 8-bit conversion of the framebuffer up to JPEG's loss — smooth content to ~1 grey level, sizes not multiples of 8"""
+    PIL = pytest.importorskip("PIL.Image")
+    pkg()
+    from ray_tracing_v06_amd import image_io
+    H, W = 53, 75
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    fb = np.ones((H, W, 4), np.float32)
+    fb[..., 0] = 0.5 + 0.5 * np.sin(xx / 9.0) * np.cos(yy / 7.0)
+    fb[..., 1] = (xx + yy) / (W + H)
+    fb[..., 2] = 0.25 + 0.5 * ((xx // 16 + yy // 16) % 2)          # hard edges too
+    path = str(tmp_path / "a.jpg")
+    image_io.write_jpg(path, fb, 95)
+    data = open(path, "rb").read()
+    assert data[:4] == b"\xff\xd8\xff\xe0" and data[6:10] == b"JFIF" and data[-2:] == b"\xff\xd9"
+    img = PIL.open(path)
+    assert img.size == (W, H) and img.mode == "RGB"
+    got = np.asarray(img).astype(np.float64)
+    exp = image_io.to_rgb8(fb).astype(np.float64)
+    mse = np.mean((got - exp) ** 2)
+    assert 10 * np.log10(255.0 ** 2 / mse) > 38.0, mse          # q95 without chroma subsampling
+    assert np.abs(got[..., 1] - exp[..., 1]).mean() < 1.5       # the smooth channel is nearly exact
+    # lower quality, smaller file, still decodable
+    image_io.write_jpg(str(tmp_path / "b.jpg"), fb, 50)
+    assert len(open(tmp_path / "b.jpg", "rb").read()) < len(data)
+    assert PIL.open(str(tmp_path / "b.jpg")).size == (W, H)

@@ -37,6 +37,7 @@ r = p.Renderer.MakeRenderer(W, H, a.spp, a.depth, cam, scene.getWorldPtr(), seed
 r.Render()
 ms = r.last_kernel_ms()
 fb = r.DownloadRenderbuffer()
-(image_io.write_ppm if a.out.endswith(".ppm") else image_io.write_png)(a.out, fb)
+# .jpg = the reference app's own format (stbi_write_jpg quality 95, FirstApp.cpp:120); .ppm / .png are lossless
+(image_io.write_ppm if a.out.endswith(".ppm") else image_io.write_jpg if a.out.endswith((".jpg", ".jpeg")) else image_io.write_png)(a.out, fb)
 print(json.dumps({"scene": a.scene, "width": W, "height": H, "spp": a.spp, "max_depth": a.depth, "render_ms": round(ms, 3),
                   "msamples_per_s": round(W * H * a.spp / ms / 1e3, 1), "out": a.out}))
