@@ -1,7 +1,8 @@
 /*
  * rt_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
- * See rt_oracle.h for the pin status ("parity unpinned" above the GLM
- * vocabulary) and the arithmetic contract.  Build: oracle/Makefile
+ * See rt_oracle.h for the pin status (pinned to the reference: the GLM vocabulary, aabb, HittableList /
+ * bvh_node traversal, checker_texture, Ray::at / isBackfacing; "parity unpinned": the sphere test, the
+ * flat BVH, Scatter, cameras, sample_world, render_kernel) and the arithmetic contract.  Build: oracle/Makefile
  * (gcc -O2 -ffp-contract=off, no fast-math).
  *
  * Citations are file:line under /root/reference/ ; "…/geometry" =

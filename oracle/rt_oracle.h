@@ -8,20 +8,22 @@
  * library, and only as the checker.  The product (librt06.so) never links,
  * loads or calls it.
  *
- * PIN STATUS.  The reference is CUDA C++ (cuda_runtime.h, curand_kernel.h,
- * <<<>>> launches); none of its translation units on this path compile in
- * this image without stand-in headers, so the reference itself is
- * UNBUILDABLE here and it ships no golden vectors (its one gtest,
- * google_testing/test.cpp, depends on cuRAND's host stream).  What IS pinned:
- * the vector-math vocabulary (GLM 0.9.9.7 vendored under Libraries/include/glm
- * and main/src/utilities/glm_utils.h) compiles with plain g++ from where it
- * lies; oracle/ref_glm_probe.cpp builds it into oracle/_ref/ and generates
- * tests/golden/glm_*.f32, against which every orc_glm_* function here is
- * checked bit-for-bit.  Everything above that vocabulary (aabb::intersects,
- * sphere test, BVH traversal, Scatter, cameras, sample_world, render_kernel)
- * is restated by hand from the source text: PARITY UNPINNED against an
- * executing reference.  The RNG is the build's own counter-seeded generator
- * (the reference's cuRAND XORWOW streams are not reproducible offline).
+ * PIN STATUS.  The reference is CUDA C++.  What of it compiles in this image with plain g++ (NVIDIA's own <cuda_runtime.h> ships
+ * inside the image's triton wheel; no stand-in headers are written) is compiled from where it lies into oracle/_ref/ and used
+ * to generate committed fixtures, against which this file is checked bit for bit (tests/test_oracle_golden.py,
+ * tests/test_reference_pins.py):
+ *   - vendored GLM 0.9.9.7 + main/src/utilities/glm_utils.h            -> tests/golden/glm_*      every orc_glm_* function
+ *   - rt_engine/geometry/aabb.cuh                                       -> ref_aabb_*, ref_aabbmisc_*  aabb_intersects, box_* helpers
+ *   - rt_engine/geometry/HittableList.cuh, bvh_node.cuh (probe leaves)  -> ref_agg_*              list_/tree_closest_intersection
+ *   - rt_engine/shaders/cu_Textures.cuh                                 -> ref_checker_*          checker_value
+ *   - rt_engine/ray_data.cuh, geometry/BVH.cuh (layouts)                -> ref_ray_*, ref_layout.json
+ * PARITY UNPINNED against an executing reference — the files do not build here (cuError.h needs <format>, cuda_utils.cuh
+ * and Renderer.cu contain <<<>>>, cuRandom.cuh needs curand_kernel.h) and the reference ships no golden vectors (its one
+ * gtest depends on cuRAND's host stream): _sphere_closest_intersection and the sphere hittables, BVH::ClosestIntersection
+ * and the builders, Scatter, the cameras, sample_world, render_kernel, the scene generators — restated by hand from the
+ * source text.  Their outputs of today are frozen in tests/golden/frozen_*.npz (oracle/gen_frozen.py) so that oracle and
+ * kernels cannot drift together unnoticed.  The RNG is the build's own counter-seeded generator (the reference's cuRAND
+ * XORWOW streams are not reproducible offline); Philox is pinned against the Random123 known-answer vectors.
  *
  * Arithmetic contract (shared with the HIP kernels): IEEE fp32, no FMA
  * contraction (-ffp-contract=off), correctly rounded / and sqrtf, GLM's

@@ -400,6 +400,36 @@ def test_tile_sharding_is_gpu_count_invariant(p, world_size):
     assert got.tobytes() == ref.tobytes()
 
 
+def test_download_after_render_async_on_a_side_stream_is_ordered(p):
+    """rt_renderer_render_async(r, caller_stream, NULL) renders into the renderer's own framebuffer; DownloadRenderbuffer must wait for
+    THAT stream's work (the renderer's own stream is non-blocking, so syncing it alone would copy a stale or partial frame)."""
+    import torch
+    W, H, spp = 400, 300, 40
+    s = config_scene(p, "book1_final")
+    cam = config_cameras(p, "book1_final", W, H)
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr())
+    r.Render()
+    ref = r.DownloadRenderbuffer()
+    r.close()
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr())
+    side = torch.cuda.Stream()
+    r.render_async(side.cuda_stream, None)
+    got = r.DownloadRenderbuffer()          # no explicit synchronisation by the caller
+    r.close()
+    assert got.tobytes() == ref.tobytes()
+    # rt_renderer_kernel_times: per-kernel HIP-event durations of the last renders (what bench.py prices the roofline with)
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr())
+    with pytest.raises(p.capi.RtError):
+        r.kernel_times(0)
+    r.Render(); r.Render()
+    t_primary, t_stream, t_resolve = r.kernel_times(0)
+    assert 0 < t_primary < t_stream and 0 < t_resolve < t_stream
+    assert abs(sum(r.kernel_times(1)) - sum(r.kernel_times(0))) < 0.5 * sum(r.kernel_times(0))
+    with pytest.raises(p.capi.RtError):
+        r.kernel_times(2)
+    r.close()
+
+
 def test_bad_world_is_refused_not_faulted(p):
     """Indices are validated on the host before any kernel follows them."""
     s = p.Scene.book1_final(1)
