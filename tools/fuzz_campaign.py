@@ -57,7 +57,7 @@ def make_world(rng):
     if rng.random() < 0.5:
         s.MakeSphere((0, -500.0, 0), 498.0, surf[int(rng.integers(0, 4))])
     if kinds >= 1:
-        quad_mats = [m for m in surf if m != (mats[-1] if kinds >= 3 else -1)]   # no image texture on quads
+        quad_mats = list(surf)   # incl. the image texture (round 2: (u, v) = the planar coordinates of the hit)
         for _ in range(int(rng.integers(1, 25))):
             Q = ((rng.random(3) * 2 - 1) * np.array([spread, 3, spread])).astype(np.float32)
             if rng.random() < 0.4:
@@ -69,8 +69,11 @@ def make_world(rng):
             s.MakeBox((-1, 0, -1), (1.5, 2, 1), quad_mats[0], float(rng.uniform(-40, 40)), (rng.random(3) * 4).astype(np.float32))
         if rng.random() < 0.6:
             s.set_background(tuple(float(x) for x in rng.random(3) * 0.4))
-    builder = int(rng.integers(0, 4)) if not big else int(rng.integers(0, 2))
+    # big worlds: the two O(n log n) builders, and (round 2) now and then a HittableList — the global-memory form of the list kernel
+    builder = int(rng.integers(0, 4)) if not big else (3 if rng.random() < 0.08 else int(rng.integers(0, 2)))
     [s.BuildBVH_TopDown, s.BuildBVH_SAH, s.BuildBVH_BottomUp, s.MakeHittableList][builder]()
+    if builder != 3 and rng.random() < 0.05:
+        s.set_traversal(1)   # the distance-sorted queue (baseline kernel): an overflow of its 32 entries is a refusal, not a failure
     return s, kinds, builder, big
 
 
@@ -100,9 +103,20 @@ for seed in range(args.first, args.first + args.seeds):
         stats["refused"] = stats.get("refused", 0) + 1   # e.g. variant 4 on an extended world, variant 3 on a HittableList
         continue
     info = r.kernel_info()
-    r.Render()
-    img = r.DownloadRenderbuffer()
+    try:
+        r.Render()
+        img = r.DownloadRenderbuffer()
+    except p.capi.RtError as e:
+        if e.code != 4:
+            raise
+        stats["queue_overflow"] = stats.get("queue_overflow", 0) + 1
+        r.close()
+        continue
     r.close()
+    if big and builder == 3:
+        W, H, spp = min(W, 40), min(H, 24), min(spp, 3)   # (a 2000-sphere list costs the CPU oracle 2000 sphere tests per ray)
+        r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w, variant=variant)
+        r.Render(); img = r.DownloadRenderbuffer(); r.close()
     ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
     stats["baseline" if info["variant"] == 1 else ("lds" if info["lds_resident"] else "global")] += 1
     if info["variant"] == 1:
