@@ -381,6 +381,7 @@ def main():
     for rr in rs:
         rr.close()
     if world_size > 1:
+        dist.barrier()   # rank 0 may still be verifying the assembled frame: nobody tears the group down before it is done
         dist.destroy_process_group()
 
 
