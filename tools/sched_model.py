@@ -26,6 +26,7 @@ ap.add_argument("--c-shade", type=float, default=7.0)    # shade body of one rou
 ap.add_argument("--c-regen", type=float, default=1.7)    # regeneration part of a round
 ap.add_argument("--c-begin", type=float, default=2.0)    # begin-trace part of a round (or of a swap phase)
 ap.add_argument("--c-swap", type=float, default=0.4)     # register moves + path-state traffic of a swap phase
+ap.add_argument("--first-leaf", type=int, default=8)    # inner steps before the first leaf can appear
 ap.add_argument("--seed", type=int, default=1)
 a = ap.parse_args()
 rnd = random.Random(a.seed)
@@ -39,8 +40,11 @@ def new_trace():
     k = int(np.searchsorted(cum, rnd.random()))
     H, L = divmod(k, h.shape[1])
     ev = ['I'] * H
+    # a trace walks ~8 levels down before it can meet its first leaf (488 leaves, median split: leaves sit at depth 8-9), so
+    # the leaf tests fall into the later part of the trace
+    first = min(H, a.first_leaf)
     for _ in range(L):
-        ev.insert(rnd.randint(1 if H else 0, len(ev)), 'L')
+        ev.insert(rnd.randint(first, len(ev)), 'L')
     return ev
 
 class Lane:
