@@ -53,9 +53,13 @@ RT_HD bool aabb_intersects(f3 box_min, f3 box_max, const Ray& ray, float ray_max
 }
 
 // _sphere_closest_intersection, rt_engine/geometry/SphereHittable.cuh:15-33
+// `a` = dot(ray.d, ray.d) is a property of the ray: the streaming kernel computes it once per trace (same expression, same bits)
+RT_HD float sphere_closest_intersection_a(const Ray& ray, float a, f3 center, float radius);
 RT_HD float sphere_closest_intersection(const Ray& ray, f3 center, float radius) {
+    return sphere_closest_intersection_a(ray, dot(ray.d, ray.d), center, radius);
+}
+RT_HD float sphere_closest_intersection_a(const Ray& ray, float a, f3 center, float radius) {
     f3 oc = ray.o - center;
-    float a = dot(ray.d, ray.d);
     float hb = dot(ray.d, oc);
     float c = dot(oc, oc) - radius * radius;
     float d = hb * hb - a * c;

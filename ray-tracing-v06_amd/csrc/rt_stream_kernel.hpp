@@ -258,6 +258,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     f3 accum_rad = mk3(0.0f);  // EXT only: radiance emitted along the path so far
     Rng rng;
     rng.s0 = 1u; rng.s1 = 0u; rng.s2 = 0u; rng.s3 = 0u; rng.draws = 0u;   // every sample brings its own state (primary_rays_kernel)
+    float ray_a = 0.0f;     // dot(ray.d, ray.d): the `a` of every sphere test of the trace (SphereHittable.cuh:17), computed once per ray
     float rec_t = RT_MISS_DIST;
     int32_t rec_code = -1;  // leaf code of the closest hit so far, -1 = none
     uint32_t cur = K_NEED;   // node reference being visited, or the lane's status (see RT_CUR_*)
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     do {                                                                   \
         rec_t = RT_MISS_DIST;                                              \
         rec_code = -1;                                                     \
+        ray_a = dot(ray.d, ray.d);                                         \
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
             inv_d = mk3(rcp_exact_regular(ray.d.x), rcp_exact_regular(ray.d.y), rcp_exact_regular(ray.d.z)); /* used by regular rays only */ \
@@ -294,6 +296,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         bool hit_root_;                                                    \
         if (WORLD == RT_WORLD_NODE_TREE) hit_root_ = true;                 \
         else if (EXACT || !regular) hit_root_ = aabb_intersects(root_min, root_max, ray, rec_t, d_root_);         \
+        else if (WORLD == RT_WORLD_BVH && ray.o.x > root_min.x && ray.o.x < root_max.x && ray.o.y > root_min.y && ray.o.y < root_max.y &&       \
+                 ray.o.z > root_min.z && ray.o.z < root_max.z)                                                                                \
+            hit_root_ = true;  /* a regular ray that starts strictly inside the root box: every near quotient is < 0 and every far one > 0  \
+                                  (non-zero differences, finite non-zero directions, no underflow in the class), so aabb.cuh:41 is true */ \
         else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
@@ -514,7 +520,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     if (EXT && (sph_matbits >> 29) == RT_MAT_ISOTROPIC)
                         t = medium_sphere_intersection(ray, center, sph.w, mats16[sph_matbits & RT_MAT_INDEX_MASK].w, rec_t, rng);
                     else
-                        t = sphere_closest_intersection(ray, center, sph.w);
+                        t = sphere_closest_intersection_a(ray, ray_a, center, sph.w);
                     if (!(t >= rec_t)) {  // `if (t >= rec.distance) return false;`
                         rec_t = t;
                         rec_code = (int32_t)code;
