@@ -268,3 +268,25 @@ def test_bench_workload_table_builds_matching_product_and_oracle_scenes():
         assert (w.kind, w.n_nodes, w.n_prims, w.n_quads, w.n_materials) == (ow.kind, ow.n_nodes, ow.n_prims, ow.n_quads, ow.n_materials), name
         assert scene.arrays()[0].tobytes() == oscene.nodes.tobytes(), name
         assert bytes(cam) == bytes(ocam), name
+
+
+def test_bench_roofline_is_recomputable_from_the_committed_counter_summary():
+    """bench.py's `roofline` = SQ_INSTS_VALU of the newest profiles/rNN_bench_pmc_summary.csv / the live kernel time against
+    SIMDs x clock / 2: recompute it here from the committed files alone and require frac <= 1 and a source-hash stamp."""
+    import csv
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    v, src, stamp = bench.profiled_counters("render_kernel_stream")
+    assert v is not None and src.startswith("profiles/r") and stamp and len(stamp) == 64
+    stats = [r for r in csv.DictReader(open(os.path.join(ROOT, src.replace("_pmc_summary", "_kernel_stats")))) if "render_kernel_stream" in r["Name"]]
+    kernel_ms = float(stats[0]["AverageNs"]) / 1e6
+    roof = bench.issue_roofline(v, kernel_ms, 1024, 2.4)
+    assert 0.5 < roof["frac"] <= 1.0 and 0.4 < roof["lanes_active_frac"] < 1.0 and roof["lane_weighted_frac"] < roof["frac"]
+    assert abs(roof["achieved"] - v["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9) < 0.01 and roof["peak"] == 1228.8
+    # the bench line committed next to it carries the same kind of object
+    line = json.load(open(os.path.join(ROOT, src.replace("_pmc_summary.csv", ".json"))))
+    assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["frac"] <= 1.0 and line["parity"]["bit_identical"]
+    assert line["metric"].startswith("Msamples/sec") and line["scaling"] == "strong" and line["cpu_baseline"]["kind"] == "port"
