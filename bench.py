@@ -350,6 +350,12 @@ def main():
                 "bound": "valu_issue", "kernel": "render_kernel_stream", **roof, "traffic": traffic,
                 "kernel_ms": round(stream_ms, 3), "kernel_ms_source": "HIP events on the kernel's stream, mean over the timed steps (rt_renderer_kernel_times)",
                 "other_kernels_ms": {"primary_rays_kernel": round(primary_ms, 3), "resolve_kernel": round(resolve_ms, 3)},
+                # the two short kernels of a step are HBM streams: algorithmic bytes (48 B written / 12 B read per sample) over their live durations
+                "other_kernels_hbm": {
+                    "primary_rays_kernel": {"algorithmic_bytes_per_sample": 48, "GBps": round(48.0 * launch_samples / (primary_ms * 1e-3) / 1e9, 1),
+                                            "frac_of_peak": round(48.0 * launch_samples / (primary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                    "resolve_kernel": {"algorithmic_bytes_per_sample": 12, "GBps": round(12.0 * launch_samples / (resolve_ms * 1e-3) / 1e9, 1),
+                                       "frac_of_peak": round(12.0 * launch_samples / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
                 "peak_definition": f"{n_simd} SIMDs x {clock_ghz:.3f} GHz / 2 cycles per wave64 fp32 add/mul/fma (tools/bench_valu_issue.hip); compares, selects, min/max "
                                    "issue in 4 cycles and scalar instructions are not hidden, so frac = 1 is not reachable by this instruction mix",
                 "samples_per_launch": launch_samples,
