@@ -18,6 +18,7 @@ ap.add_argument("--spp", type=int, default=500)
 ap.add_argument("--depth", type=int, default=50)
 ap.add_argument("--seed", type=int, default=1984)
 ap.add_argument("--device", type=int, default=0)
+ap.add_argument("--gpus", type=int, default=1, help="> 1: tile-shard the frame over GPUs 0..N-1 of this node from this one process (rt_multi_renderer_*, one RCCL exchange)")
 ap.add_argument("--out", default="render.png")
 a = ap.parse_args()
 p = G.load_package()
@@ -33,11 +34,16 @@ elif a.scene == "book1_final":
     scene, cam = p.Scene.book1_final(a.seed), p.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
 else:
     scene, cam = p.Scene.book2_moving(a.seed), p.MotionBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.0, 1.0)
-r = p.Renderer.MakeRenderer(W, H, a.spp, a.depth, cam, scene.getWorldPtr(), seed=a.seed, device=a.device)
-r.Render()
-ms = r.last_kernel_ms()
+if a.gpus > 1:
+    r = p.MultiRenderer.MakeRenderer(W, H, a.spp, a.depth, cam, scene.getWorldPtr(), a.gpus, seed=a.seed)
+    r.Render()
+    ms = r.times()[0]     # host wall-clock of Render(): all shards, the exchange, the assembly
+else:
+    r = p.Renderer.MakeRenderer(W, H, a.spp, a.depth, cam, scene.getWorldPtr(), seed=a.seed, device=a.device)
+    r.Render()
+    ms = r.last_kernel_ms()
 fb = r.DownloadRenderbuffer()
 # .jpg = the reference app's own format (stbi_write_jpg quality 95, FirstApp.cpp:120); .ppm / .png are lossless
 (image_io.write_ppm if a.out.endswith(".ppm") else image_io.write_jpg if a.out.endswith((".jpg", ".jpeg")) else image_io.write_png)(a.out, fb)
 print(json.dumps({"scene": a.scene, "width": W, "height": H, "spp": a.spp, "max_depth": a.depth, "render_ms": round(ms, 3),
-                  "msamples_per_s": round(W * H * a.spp / ms / 1e3, 1), "out": a.out}))
+                  "msamples_per_s": round(W * H * a.spp / ms / 1e3, 1), "gpus": a.gpus, "out": a.out}))
