@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 D=gpurun_out/prof_$TAG
 rm -rf $D && mkdir -p $D
 python -c "import __graft_entry__ as G; print(G.load_package().capi.source_hash())" > $D/csrc_sha256.txt
-python bench.py --steps 10 --warmup 2 > $D/bench.json 2> $D/bench.err
+python bench.py --steps 20 --warmup 5 > $D/bench.json 2> $D/bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $D/stats.log 2>&1
 echo "stats done"
