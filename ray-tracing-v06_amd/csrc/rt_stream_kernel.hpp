@@ -296,10 +296,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         bool hit_root_;                                                    \
         if (WORLD == RT_WORLD_NODE_TREE) hit_root_ = true;                 \
         else if (EXACT || !regular) hit_root_ = aabb_intersects(root_min, root_max, ray, rec_t, d_root_);         \
-        else if (WORLD == RT_WORLD_BVH && ray.o.x > root_min.x && ray.o.x < root_max.x && ray.o.y > root_min.y && ray.o.y < root_max.y &&       \
-                 ray.o.z > root_min.z && ray.o.z < root_max.z)                                                                                \
-            hit_root_ = true;  /* a regular ray that starts strictly inside the root box: every near quotient is < 0 and every far one > 0  \
-                                  (non-zero differences, finite non-zero directions, no underflow in the class), so aabb.cuh:41 is true */ \
         else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
