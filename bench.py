@@ -174,6 +174,7 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     cores = host_cores()
+    os.environ["ORC_PIN_THREADS"] = "1"   # one oracle thread per distinct CPU of the affinity mask (pinned, core count stated)
     W, H = args.width, args.height
     oscene, ocam = make_workload(args, O, oracle=True)
     # calibrate on 1 spp, then size the sample for ~cpu_seconds of wall time
@@ -189,7 +190,7 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
               "rays": cnt.rays / n, "rng_draws": cnt.rng_draws / n}
     base = {"value": round(n / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": f"{W}x{H}x{spp}spp {args.workload}, depth {args.depth}, seed {args.seed}, {dt:.1f}s wall, "
-                      f"gcc -O2 -ffp-contract=off, pthreads over rows"}
+                      f"gcc -O2 -ffp-contract=off, {cores} pthreads over rows, each pinned to its own CPU"}
     parity = None
     if gpu_image_fn is not None:
         img = gpu_image_fn(spp)

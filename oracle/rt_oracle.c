@@ -9,10 +9,12 @@
  * main/src/rt_engine/geometry, "…/shaders" = main/src/rt_engine/shaders,
  * "glm/" = Libraries/include/glm.
  */
+#define _GNU_SOURCE   /* pthread_setaffinity_np, CPU_SET */
 #include "rt_oracle.h"
 
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -790,7 +792,19 @@ int orc_render(const orc_world* w, const orc_camera* cam, uint32_t width, uint32
     }
     if (n_threads == 1) render_worker(&jobs[0]);
     else {
-        for (int i = 0; i < n_threads; i++) pthread_create(&th[i], NULL, render_worker, &jobs[i]);
+        /* ORC_PIN_THREADS=1 (bench.py's cpu_baseline leg): worker i is pinned to the i-th CPU this process may run on, so the timed
+         * baseline uses n_threads distinct cores (on the EPYC hosts of the GPU boxes the first CPUs are distinct physical cores of socket 0) */
+        const char* pin = getenv("ORC_PIN_THREADS");
+        cpu_set_t allowed;
+        int have_mask = pin && pin[0] == '1' && sched_getaffinity(0, sizeof(allowed), &allowed) == 0;
+        int cpu = -1;
+        for (int i = 0; i < n_threads; i++) {
+            pthread_create(&th[i], NULL, render_worker, &jobs[i]);
+            if (have_mask) {
+                do { cpu++; } while (cpu < CPU_SETSIZE && !CPU_ISSET(cpu, &allowed));
+                if (cpu < CPU_SETSIZE) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpu, &one); (void)pthread_setaffinity_np(th[i], sizeof(one), &one); }
+            }
+        }
         for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
     }
     int err = 0;
