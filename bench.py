@@ -46,7 +46,7 @@ WORKLOADS = {
     "cornell_box": ("cornell_box", "PinholeCamera", ((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, None), "camera_pinhole",
                     600, 600, 5000, 50, "Cornell box of The Next Week (18 quads, area light; not in the reference)", "PinholeCamera vfov 40"),
     "book2_final": ("book2_final", "MotionBlurCamera", ((478, 278, -600), (278, 278, 0), (0, 1, 0), 40.0, None, 0.0, 1.0), "camera_motion",
-                    800, 800, 1000, 40, "final scene of The Next Week (2401 quads, 1008 spheres, media, Perlin, image texture; not in the reference)",
+                    3840, 2160, 10000, 50, "final scene of The Next Week (2401 quads, 1008 spheres, media, Perlin, image texture; not in the reference)",
                     "MotionBlurCamera vfov 40 shutter 0..1"),
 }
 
@@ -110,26 +110,37 @@ def host_cores():
     return n
 
 
-def profiled_counters(kernel_substr):
-    """Per-launch hardware counters of the dominant kernel from the newest committed rocprofv3 summary
-    (profiles/rNN_bench_pmc_summary.csv: separate --pmc passes of this same command, tools/profile_round.sh).
-    Returns (counters dict, relative path, source hash the file was stamped with) or (None, None, None)."""
+def profiled_counters(kernel_substr, workload, W, H, spp, depth):
+    """Per-launch hardware counters of the dominant kernel from the newest committed rocprofv3 summary of THIS workload at this
+    frame size and depth (profiles/rNN_<name>_pmc_summary.csv, name = `bench` for the headline, else the workload; separate --pmc
+    passes of this same command: tools/profile_round.sh, tools/profile_workload.sh).  A summary taken at another spp is scaled
+    linearly to this run's samples (instruction counts are per sample; reported as counters_scaled_from_spp).
+    Returns (counters dict, relative path, hash of the library build it was taken from, spp it was taken at) or four Nones."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc_summary.csv")))
-    if not files:
-        return None, None, None
-    lines = open(files[-1]).read().splitlines()
-    stamp = None
-    while lines and lines[0].startswith("#"):
-        if "csrc_sha256:" in lines[0]:
-            stamp = lines[0].split("csrc_sha256:")[1].strip()
-        lines.pop(0)
-    v = {}
-    for row in csv.DictReader(lines):
-        if kernel_substr in row["kernel"]:
-            v[row["counter"]] = float(row["mean_per_dispatch"])
-    return (v or None), os.path.relpath(files[-1], ROOT), stamp
+    legacy = {"bench": ("book1_final", 1200, 800, 500, 50), "book2_moving": ("book2_moving", 800, 800, 1000, 50),
+              "cornell_box": ("cornell_box", 600, 600, 5000, 50), "book2_final": ("book2_final", 800, 800, 200, 40)}   # rounds 1-2: no config line
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")), reverse=True):
+        name = os.path.basename(path).split("_", 1)[1][:-len("_pmc_summary.csv")]
+        lines = open(path).read().splitlines()
+        stamp, cfg = None, legacy.get(name)
+        while lines and lines[0].startswith("#"):
+            if "csrc_sha256:" in lines[0]:
+                stamp = lines[0].split("csrc_sha256:")[1].strip()
+            if "config:" in lines[0]:
+                f = lines[0].split("config:")[1].split()
+                cfg = (f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]))
+            lines.pop(0)
+        if cfg is None or cfg[:3] != (workload, W, H) or cfg[4] != depth:
+            continue
+        # (profiles are taken at an spp that fits ONE pass, so mean_per_dispatch is the count of the whole cfg[3]-spp frame)
+        v = {}
+        for row in csv.DictReader(lines):
+            if kernel_substr in row["kernel"]:
+                v[row["counter"]] = float(row["mean_per_dispatch"]) * spp / cfg[3]
+        if v:
+            return v, os.path.relpath(path, ROOT), stamp, cfg[3]
+    return None, None, None, None
 
 
 def issue_roofline(v, kernel_ms, n_simd, clock_ghz):
@@ -296,7 +307,9 @@ def main():
     kernel_ms_source = "HIP events around every launch of the timed region"
     # per-kernel durations of the timed steps: HIP events the renderer records on the stream its kernels run on (ring of 32 renders)
     per_kernel = []
-    if args.variant != 1:
+    kinfo = rs[0].kernel_info()
+    pinfo = rs[0].pass_info()
+    if kinfo["variant"] >= 2:   # the resolved variant: a world the streaming kernels cannot take falls back to the baseline kernel under variant 0
         n_back = min(args.steps, 32 * depth)
         for k in range(n_back):
             rr = rs[(frame[0] - 1 - k) % depth]
@@ -336,8 +349,9 @@ def main():
         if counts is not None:
             bytes_per_sample = 32.0 * counts["box_tests"] + 16.0 * counts["leaf_tests"] + 16.0 * counts["shaded_hits"] + 16.0 / spp
             launch_samples = total_samples / world_size
-            default_cfg = (args.workload, W, H, spp, args.depth, args.variant, world_size) == ("book1_final", 1200, 800, 500, 50, 0, 1)
-            pmc, pmc_src, pmc_stamp = profiled_counters("render_kernel_stream") if default_cfg else (None, None, None)
+            dominant = "render_kernel_xchg" if kinfo["variant"] == 5 else "render_kernel_stream"
+            pmc, pmc_src, pmc_stamp, pmc_spp = (profiled_counters(dominant, args.workload, W, H, spp, args.depth)
+                                                if (world_size == 1 and args.variant == 0) else (None, None, None, None))
             info = pkg.api.device_info(local_rank)
             n_simd, clock_ghz = info["compute_units"] * 4, info["clock_khz"] / 1e6
             roof = issue_roofline(pmc, stream_ms, n_simd, clock_ghz) or {"achieved": None, "peak": round(n_simd * clock_ghz / 2.0, 2),
@@ -346,21 +360,24 @@ def main():
             if pmc and "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 # MI355X_MICROARCH.md, HBM section: both counters are in KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request on wide reads
                 traffic = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-            lib_hash = pkg.capi.source_hash()
+            lib_hash = pkg.capi.library_hash()   # embedded in the loaded librt06.so at build time: the BINARY's provenance
             out["roofline"] = {
-                "bound": "valu_issue", "kernel": "render_kernel_stream", **roof, "traffic": traffic,
-                "kernel_ms": round(stream_ms, 3), "kernel_ms_source": "HIP events on the kernel's stream, mean over the timed steps (rt_renderer_kernel_times)",
+                "bound": "valu_issue", "kernel": dominant, **roof, "traffic": traffic,
+                "kernel_ms": round(stream_ms, 3), "kernel_ms_source": "HIP events on the kernel's stream, summed over the passes of a step, mean over the timed steps (rt_renderer_kernel_times)",
+                "passes_per_step": pinfo["n_passes"], "spp_per_pass": pinfo["pass_spp"],
+                "counters_scaled_from_spp": (None if pmc_spp in (None, spp) else pmc_spp),
                 "other_kernels_ms": {"primary_rays_kernel": round(primary_ms, 3), "resolve_kernel": round(resolve_ms, 3)},
-                # the two short kernels of a step are HBM streams: algorithmic bytes (48 B written / 12 B read per sample) over their live durations
+                # the two short kernels of a step are HBM streams: algorithmic bytes (48 B written / 16 B read per sample) over their live durations
                 "other_kernels_hbm": {
                     "primary_rays_kernel": {"algorithmic_bytes_per_sample": 48, "GBps": round(48.0 * launch_samples / (primary_ms * 1e-3) / 1e9, 1),
                                             "frac_of_peak": round(48.0 * launch_samples / (primary_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                    "resolve_kernel": {"algorithmic_bytes_per_sample": 12, "GBps": round(12.0 * launch_samples / (resolve_ms * 1e-3) / 1e9, 1),
-                                       "frac_of_peak": round(12.0 * launch_samples / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
+                    "resolve_kernel": {"algorithmic_bytes_per_sample": 16, "GBps": round(16.0 * launch_samples / (resolve_ms * 1e-3) / 1e9, 1),
+                                       "frac_of_peak": round(16.0 * launch_samples / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
                 "peak_definition": f"{n_simd} SIMDs x {clock_ghz:.3f} GHz / 2 cycles per wave64 fp32 add/mul/fma (tools/bench_valu_issue.hip); compares, selects, min/max "
                                    "issue in 4 cycles and scalar instructions are not hidden, so frac = 1 is not reachable by this instruction mix",
                 "samples_per_launch": launch_samples,
                 "counters_source": pmc_src, "counters_source_csrc_sha256": pmc_stamp, "library_csrc_sha256": lib_hash,
+                "library_matches_tree_sources": bool(lib_hash == pkg.capi.source_hash()),
                 "counters_stale": (None if pmc_src is None else bool(pmc_stamp != lib_hash)),
                 "counts_per_sample": {k: round(v, 3) for k, v in counts.items()},
                 "hbm": {"note": "secondary: the scene (60 KB) is LDS-resident, the algorithmic bytes are served from the LDS and HBM is not the roof",

@@ -293,9 +293,15 @@ int rt_renderer_render_async(rt_renderer* r, void* hip_stream, float* d_out);
  * Renderer.cu:127-136).  Synchronises on the events.                        */
 int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms);
 /* Per-kernel HIP-event times (ms) of one of the last 32 render calls (renders_back = 0: the most recent), measured on the
- * stream the kernels ran on: out[0] = primary_rays_kernel, out[1] = render_kernel_stream (the dominant kernel),
- * out[2] = resolve_kernel — of the call's last pass.  Synchronises on that call's end.  Streaming variants (>= 2) only. */
+ * stream the kernels ran on: out[0] = primary_rays_kernel, out[1] = the dominant kernel (render_kernel_stream /
+ * render_kernel_xchg), out[2] = resolve_kernel — each SUMMED over the passes of that call (rt_renderer_pass_info).
+ * Synchronises on that call's end.  Streaming variants (>= 2) only.                                                       */
 int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms[3]);
+/* How a render is cut into passes: out[0] = passes per render, out[1] = samples per pixel per pass, out[2] = HBM bytes per
+ * sample index of a pass (16 B radiance + 48 B primary-ray record), out[3] = bytes of the per-pass buffers this renderer
+ * holds (sample buffer + primary rays + running sums).  A pass is sized by a budget over ALL of those buffers: 40 GiB by
+ * default, RT06_PASS_BUDGET_BYTES to change it, RT06_PASS_SPP to force the samples per pixel per pass (tests).           */
+int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]);
 /* Which kernel the renderer resolved to: out[0] = variant actually used (1..4), out[1] = 1 when the scene image is
  * LDS-resident (0: baseline kernel, or a world too large for the LDS, served from global memory / L2 with 32-bit
  * references), out[2] = workgroup size, out[3] = workgroups per CU.                                              */
@@ -317,7 +323,10 @@ int rt_renderer_assemble(rt_renderer* r, const float* d_gathered, float* d_image
 /* The reference is single-GPU.  Rank i = devices[i] (NULL: 0 .. n_gpus-1) renders the 8x8 tiles t with
  * t % n_gpus == i; ONE grouped RCCL exchange over xGMI (ncclSend from every rank, ncclRecv on rank 0) gathers the shards
  * on devices[0] at frame end and a de-interleave kernel assembles the row-major frame there.  cfg->device / rank /
- * world_size are ignored.  The image has the same bits for every n_gpus.  RCCL (librccl.so.1) is bound at first use.    */
+ * world_size are ignored.  The image has the same bits for every n_gpus.  RCCL (librccl.so.1) is bound at first use.
+ * RT06_MULTI_TRANSPORT=memcpy (tests, single-GPU boxes) replaces the RCCL exchange by hipMemcpyAsync on the ranks' own
+ * streams and lifts the one-rank-per-device rule (devices may repeat; NULL = i % device count), so that the N > 1 branch
+ * — shard offsets, stream ordering, assembly, download — runs on ONE GPU, where RCCL refuses two ranks.                 */
 typedef struct rt_multi_renderer rt_multi_renderer;
 int rt_multi_renderer_create(const rt_render_config* cfg, const rt_camera* cam, const rt_world_flat* world,
                              uint32_t n_gpus, const int32_t* devices, rt_multi_renderer** out);
@@ -414,6 +423,9 @@ int rt_device_count(int* out);
 /* out = {compute units, peak engine clock in kHz, device memory in MiB, memory clock in kHz} (hipDeviceProp_t) */
 int rt_device_info(int device, uint32_t out[4]);
 const char* rt_version(void);
+/* sha256 (hex) over the sources, Makefile and extra flags this library was built from (csrc/Makefile: SRC_HASH): committed
+ * profiler summaries are stamped with it, so a stale binary cannot pass for the profiled one.                             */
+const char* rt_source_hash(void);
 
 #ifdef __cplusplus
 }

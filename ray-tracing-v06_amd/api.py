@@ -269,10 +269,16 @@ class Renderer:
         return ms.value
 
     def kernel_times(self, renders_back=0):
-        """(primary_rays_kernel, render_kernel_stream, resolve_kernel) ms of one of the last 32 render calls, by HIP events."""
+        """(primary_rays_kernel, dominant kernel, resolve_kernel) ms of one of the last 32 render calls, by HIP events, summed over its passes."""
         out = (C.c_float * 3)()
         check(lib().rt_renderer_kernel_times(self.h, renders_back, out))
         return tuple(out)
+
+    def pass_info(self):
+        """{'n_passes', 'pass_spp', 'bytes_per_sample', 'buffer_bytes'}: how a render is cut into passes (rt_renderer_pass_info)."""
+        out = (C.c_uint64 * 4)()
+        check(lib().rt_renderer_pass_info(self.h, out))
+        return {"n_passes": out[0], "pass_spp": out[1], "bytes_per_sample": out[2], "buffer_bytes": out[3]}
 
     def kernel_info(self):
         """{'variant', 'lds_resident', 'workgroup', 'workgroups_per_cu'} the renderer resolved to."""

@@ -72,23 +72,31 @@ SYMBOLS = [
     "rt_renderer_assemble", "rt_renderer_kernel_times", "rt_multi_renderer_create", "rt_multi_renderer_destroy", "rt_multi_renderer_render",
     "rt_multi_renderer_download", "rt_multi_renderer_times", "rt_multi_renderer_gpus", "rt_shard_layout", "rt_shard_pixel_map", "rt_device_info", "rt_scene_set_traversal", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
     "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_math", "rt_probe_glm", "rt_probe_aabb_misc", "rt_probe_aabb_regular", "rt_probe_boxpair_filtered",
-    "rt_selftest_fastdiv", "rt_selftest_fastdiv4", "rt_selftest_fastrcp", "rt_device_count", "rt_version",
+    "rt_selftest_fastdiv", "rt_selftest_fastdiv4", "rt_selftest_fastrcp", "rt_device_count", "rt_version", "rt_source_hash", "rt_renderer_pass_info",
 ]
 
 _lib = None
 
 
 def source_hash():
-    """sha256 over the sources librt06.so is built from (csrc/*, include/rt06.h), in name order: stamps the committed
-    rocprofv3 counter summaries so that bench.py can tell whether they describe the library that is running."""
+    """sha256 over the sources librt06.so is built from, exactly as csrc/Makefile computes it for the stamp it embeds in the
+    library (SRCS, HDRS, the Makefile, the EXTRA flags of a plain build): the hash a fresh `make` of this tree WOULD embed."""
     import hashlib
+    import re
+    mk = open(os.path.join(CSRC_DIR, "Makefile")).read()
+    names = re.search(r"^SRCS\s*:=\s*(.*)$", mk, re.M).group(1).split() + re.search(r"^HDRS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    files = [os.path.join(os.path.dirname(PKG_DIR), "include", "rt06.h") if n.endswith("rt06.h") else os.path.join(CSRC_DIR, n) for n in names]
+    files.append(os.path.join(CSRC_DIR, "Makefile"))
     h = hashlib.sha256()
-    files = sorted(os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile")
-    files.append(os.path.join(os.path.dirname(PKG_DIR), "include", "rt06.h"))
     for f in files:
-        h.update(os.path.basename(f).encode() + b"\0")
         h.update(open(f, "rb").read())
+    h.update(b"\n")   # echo "$(EXTRA)" of a plain build
     return h.hexdigest()
+
+
+def library_hash():
+    """The source hash embedded in the librt06.so that is actually loaded (rt_source_hash): what the running BINARY was built from."""
+    return lib().rt_source_hash().decode()
 
 
 def build_native(force=False):
@@ -132,6 +140,8 @@ def lib():
     P = C.POINTER
     L.rt_last_error.restype = C.c_char_p
     L.rt_version.restype = C.c_char_p
+    L.rt_source_hash.restype = C.c_char_p
+    L.rt_renderer_pass_info.argtypes = [C.c_void_p, C.c_uint64 * 4]
     L.rt_camera_pinhole.argtypes = [vec3, vec3, vec3, C.c_float, C.c_float, P(Camera)]
     L.rt_camera_defocus.argtypes = [vec3, vec3, vec3, C.c_float, C.c_float, C.c_float, C.c_float, P(Camera)]
     L.rt_camera_motion.argtypes = [vec3, vec3, vec3, C.c_float, C.c_float, C.c_float, C.c_float, P(Camera)]

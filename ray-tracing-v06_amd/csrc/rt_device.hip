@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <algorithm>
 #include <memory>
+#include <mutex>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <utility>
@@ -402,7 +404,7 @@ struct rt_renderer {
     TileMap tm{};
     DevBuf fb;
     DevBuf work_counter;
-    DevBuf samples, running;     // sample buffer of one pass; running sums when spp needs several passes
+    DevBuf samples, running;     // sample buffer of one pass (16 B per sample); running sums (16 B per pixel) when spp needs several passes
     // primary rays of one pass: 3 arrays of 16 B per sample index (origin|time, direction, RNG state).  Generated on the render's
     // own stream, before the streaming kernel: generating pass k + 1 on a second stream WHILE pass k is traced was measured and is
     // harmful (the persistent kernel ran 40 % slower with the generator's waves co-resident: 100 ms instead of 70).
@@ -419,11 +421,14 @@ struct rt_renderer {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
-    // per-kernel HIP events of the last RT_TIMES_RING render calls (last pass of each), on the stream the kernels run on:
-    // [0] before primary_rays_kernel, [1] before the streaming kernel, [2] after it, [3] after resolve_kernel
+    // per-kernel HIP events of the last RT_TIMES_RING render calls, on the stream the kernels run on, four per PASS:
+    // [4k] before primary_rays_kernel of pass k, [4k+1] before the streaming kernel, [4k+2] after it, [4k+3] after resolve_kernel.
+    // Created at first use (a 10 000-spp render of a 4K frame has > 100 passes).
     static constexpr uint32_t RT_TIMES_RING = 32;
-    hipEvent_t kev[RT_TIMES_RING][4] = {};
+    std::vector<hipEvent_t> kev[RT_TIMES_RING];
     uint64_t n_renders = 0;
+    uint32_t n_passes = 1;
+    static constexpr uint32_t SAMPLE_BYTES = 16, PRIMARY_BYTES = 48;   // HBM per sample index of a pass: radiance (float4) + primary ray record
 
     // Pick the kernel variant and size the per-pass sample buffer.
     //   0 = default (the fastest validated variant), 1 = baseline wave-per-pixel kernel,
@@ -484,18 +489,27 @@ struct rt_renderer {
             }
         }
         if (variant >= 2) {
-            uint64_t budget = 8ull << 30;  // HBM for one pass of per-sample radiance (12 B each; the primary-ray records add 48 B each)
-            if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // tests force multi-pass rendering with this
+            // HBM of one pass: every sample index owns SAMPLE_BYTES of radiance + PRIMARY_BYTES of primary-ray record.  The default
+            // budget (40 GiB of the 288) gives the 1200x800x500 headline one pass (30.7 GB) and a 3840x2160 frame 80 spp per pass.
+            uint64_t budget = 40ull << 30;
+            const uint64_t per_sample = SAMPLE_BYTES + PRIMARY_BYTES;
+            if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // bytes of ALL per-sample buffers of a pass
                 unsigned long long v = std::strtoull(env, nullptr, 10);
-                if (v >= 12) budget = v;
+                if (v >= per_sample) budget = v;
             }
             uint64_t n_local_pixels = (uint64_t)tm.n_local_tiles * RT_TILE * RT_TILE;
-            uint64_t max_spp = std::max<uint64_t>(1, budget / (n_local_pixels * 12ull));
+            uint64_t max_spp = std::max<uint64_t>(1, budget / (n_local_pixels * per_sample));
+            if (const char* env = std::getenv("RT06_PASS_SPP")) {  // tests force multi-pass rendering with this
+                unsigned long long v = std::strtoull(env, nullptr, 10);
+                if (v >= 1) max_spp = v;
+            }
+            max_spp = std::min<uint64_t>(max_spp, (0xF0000000ull - 1) / n_local_pixels);   // sample indices of a pass are 32 bits wide
+            if (max_spp == 0) return rt_fail(RT_ERR_INVALID, "image too large for one pass");
             pass_spp = (uint32_t)std::min<uint64_t>(cfg.samples_per_pixel, max_spp);
-            if (n_local_pixels * pass_spp >= 0xF0000000ull) return rt_fail(RT_ERR_INVALID, "image too large for one pass");
-            HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * 12ull)));
-            HIP_TRY(primary[0].alloc((size_t)(n_local_pixels * pass_spp * 48ull)));
-            if (pass_spp < cfg.samples_per_pixel) HIP_TRY(running.alloc((size_t)(n_local_pixels * 12ull)));
+            n_passes = (cfg.samples_per_pixel + pass_spp - 1) / pass_spp;
+            HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * SAMPLE_BYTES)));
+            HIP_TRY(primary[0].alloc((size_t)(n_local_pixels * pass_spp * PRIMARY_BYTES)));
+            if (n_passes > 1) HIP_TRY(running.alloc((size_t)(n_local_pixels * 16ull)));
             HIP_TRY(hipFuncSetAttribute(stream_kernel_ptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
             if (std::getenv("RT06_DEBUG")) {
                 int occ = -1;
@@ -560,12 +574,19 @@ struct rt_renderer {
         p.tm = tm;
         p.scene = scene.packed;
         p.scene.n_top = scene.big ? n_top : 0u;
-        p.samples = samples.as<float>();
+        p.samples = samples.as<float4>();
         p.work_counter = work_counter.as<uint32_t>();
         p.inner_keep = tune[0] ? tune[0] : 1u; p.shade_min = tune[1]; p.leaf_min = tune[2];
         uint32_t n_local_pixels = tm.n_local_tiles * RT_TILE * RT_TILE;
         uint32_t grid = n_cus * stream_blocks_per_cu;
-        for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp) {
+        std::vector<hipEvent_t>& ring = kev[n_renders % RT_TIMES_RING];
+        while (ring.size() < (size_t)n_passes * 4u) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            ring.push_back(e);
+        }
+        uint32_t pass = 0;
+        for (uint32_t first = 0; first < cfg.samples_per_pixel; first += pass_spp, pass++) {
             p.pass_first_s = first;
             p.pass_spp = std::min(pass_spp, cfg.samples_per_pixel - first);
             p.total = n_local_pixels * p.pass_spp;
@@ -583,7 +604,7 @@ struct rt_renderer {
             p.phase_acc = phase_acc.as<unsigned long long>();
 #endif
             const int pb = 0;
-            hipEvent_t* ke = kev[n_renders % RT_TIMES_RING];
+            hipEvent_t* ke = ring.data() + (size_t)pass * 4u;
             HIP_TRY(hipEventRecord(ke[0], st));
             {
                 const size_t n_pass = (size_t)tm.n_local_tiles * RT_TILE * RT_TILE * pass_spp;   // 16-B records per array
@@ -621,7 +642,7 @@ struct rt_renderer {
             }
 #endif
             uint32_t last = first + p.pass_spp >= cfg.samples_per_pixel ? 1u : 0u;
-            resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float>(), out, last);
+            resolve_kernel<<<(n_local_pixels + 255) / 256, 256, 0, st>>>(p, running.as<float4>(), out, last);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(ke[3], st));
         }
@@ -664,7 +685,6 @@ extern "C" int rt_renderer_create(const rt_render_config* cfg, const rt_camera* 
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&r->ev0);
     if (e == hipSuccess) e = hipEventCreate(&r->ev1);
-    for (auto& q : r->kev) for (hipEvent_t& ke : q) if (e == hipSuccess) e = hipEventCreate(&ke);
     if (e != hipSuccess) { delete r; return rt_fail(RT_ERR_HIP, "rt_renderer_create: %s", hipGetErrorString(e)); }
     *out = r;
     return RT_OK;
@@ -712,9 +732,24 @@ extern "C" int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, f
         return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_times: render %u calls back is not recorded (%llu rendered, ring of %u)", renders_back,
                        (unsigned long long)r->n_renders, rt_renderer::RT_TIMES_RING);
     HIP_TRY(hipSetDevice(r->cfg.device));
-    hipEvent_t* ke = r->kev[(r->n_renders - 1 - renders_back) % rt_renderer::RT_TIMES_RING];
-    HIP_TRY(hipEventSynchronize(ke[3]));
-    for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(out_ms + k, ke[k], ke[k + 1]));
+    const std::vector<hipEvent_t>& ring = r->kev[(r->n_renders - 1 - renders_back) % rt_renderer::RT_TIMES_RING];
+    HIP_TRY(hipEventSynchronize(ring[(size_t)r->n_passes * 4u - 1u]));
+    for (int k = 0; k < 3; k++) out_ms[k] = 0.0f;
+    for (uint32_t pass = 0; pass < r->n_passes; pass++)   // a render is n_passes launches of each kernel: the SUM is the render's time in it
+        for (int k = 0; k < 3; k++) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, ring[pass * 4u + k], ring[pass * 4u + k + 1]));
+            out_ms[k] += ms;
+        }
+    return RT_OK;
+}
+
+extern "C" int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]) {
+    if (!r || !out) return rt_fail(RT_ERR_INVALID, "rt_renderer_pass_info: null argument");
+    out[0] = r->variant >= 2 ? r->n_passes : 1u;
+    out[1] = r->variant >= 2 ? r->pass_spp : r->cfg.samples_per_pixel;
+    out[2] = r->variant >= 2 ? rt_renderer::SAMPLE_BYTES + rt_renderer::PRIMARY_BYTES : 0u;
+    out[3] = r->samples.bytes + r->primary[0].bytes + r->running.bytes;
     return RT_OK;
 }
 
@@ -789,9 +824,11 @@ struct RcclApi {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 RcclApi g_rccl;
+std::once_flag g_rccl_once;
+int g_rccl_rc = RT_OK;
+std::string g_rccl_error;
 
-int rccl_bind() {
-    if (g_rccl.handle) return RT_OK;
+int rccl_bind_once() {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return rt_fail(RT_ERR_HIP, "multi-GPU rendering needs RCCL: %s", dlerror());
@@ -811,6 +848,14 @@ int rccl_bind() {
     g_rccl = a;
     return RT_OK;
 }
+// bound once per process, whichever thread creates the first multi-GPU renderer
+int rccl_bind() {
+    std::call_once(g_rccl_once, [] {
+        g_rccl_rc = rccl_bind_once();
+        if (g_rccl_rc != RT_OK) g_rccl_error = rt_last_error();
+    });
+    return g_rccl_rc == RT_OK ? RT_OK : rt_fail(g_rccl_rc, "%s", g_rccl_error.c_str());
+}
 }  // namespace
 
 #define RCCL_TRY(expr)                                                                                                  \
@@ -819,17 +864,31 @@ int rccl_bind() {
         if (_r != ncclSuccess) return rt_fail(RT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
     } while (0)
 
+// How the shards travel to devices[0] at frame end.
+//   RT_TRANSPORT_RCCL   (default): one grouped ncclSend / ncclRecv exchange over xGMI, one rank per GPU.
+//   RT_TRANSPORT_MEMCPY (RT06_MULTI_TRANSPORT=memcpy; tests and single-GPU boxes): hipMemcpyAsync on the ranks' own streams, ordered
+//       by events.  It lifts the one-rank-per-device rule, so N ranks can share ONE GPU and the whole N > 1 branch — shard offsets,
+//       stream ordering, assemble_kernel, download — runs where RCCL would refuse (it does not accept two ranks on one device).
+enum : uint32_t { RT_TRANSPORT_RCCL = 0, RT_TRANSPORT_MEMCPY = 1 };
+
 struct rt_multi_renderer {
     uint32_t width = 0, height = 0;
+    uint32_t transport = RT_TRANSPORT_RCCL;
     std::vector<int> devices;
     std::vector<rt_renderer*> parts;     // parts[i]: rank i of N on devices[i]
     std::vector<ncclComm_t> comms;
+    std::vector<hipEvent_t> ev_part;     // per rank, on its device: its render is enqueued / (memcpy transport) its shard has been copied
     DevBuf gathered, image;              // on devices[0]: N shards back to back; the assembled row-major frame
-    hipEvent_t ev_rendered = nullptr, ev_done = nullptr;   // on devices[0]'s stream: before the exchange / after the assembly
+    hipEvent_t ev_rendered = nullptr, ev_done = nullptr;   // on devices[0]'s stream: every rank has rendered / after the assembly
     float last_total_ms = 0.0f;
     bool rendered = false;
     ~rt_multi_renderer() {
         for (ncclComm_t c : comms) if (c) (void)g_rccl.CommDestroy(c);
+        for (size_t i = 0; i < ev_part.size(); i++) {
+            if (!ev_part[i]) continue;
+            (void)hipSetDevice(devices[i]);
+            (void)hipEventDestroy(ev_part[i]);
+        }
         for (rt_renderer* r : parts) rt_renderer_destroy(r);
         if (!devices.empty()) (void)hipSetDevice(devices[0]);
         if (ev_rendered) (void)hipEventDestroy(ev_rendered);
@@ -843,18 +902,25 @@ extern "C" int rt_multi_renderer_create(const rt_render_config* cfg, const rt_ca
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
         return rt_fail(RT_ERR_NO_DEVICE, "no HIP device available: the HIP path is required, there is no CPU fallback");
-    if (n_gpus == 0 || (int)n_gpus > n_dev) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: %u GPUs asked for, %d present", n_gpus, n_dev);
+    uint32_t transport = RT_TRANSPORT_RCCL;
+    if (const char* env = std::getenv("RT06_MULTI_TRANSPORT")) {
+        if (std::strcmp(env, "memcpy") == 0) transport = RT_TRANSPORT_MEMCPY;
+        else if (std::strcmp(env, "rccl") != 0) return rt_fail(RT_ERR_INVALID, "RT06_MULTI_TRANSPORT=%s: expected rccl or memcpy", env);
+    }
+    if (n_gpus == 0 || n_gpus > 64) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: %u ranks asked for", n_gpus);
+    if (transport == RT_TRANSPORT_RCCL && (int)n_gpus > n_dev) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: %u GPUs asked for, %d present", n_gpus, n_dev);
     std::vector<int> devs(n_gpus);
     for (uint32_t i = 0; i < n_gpus; i++) {
-        devs[i] = devices ? devices[i] : (int)i;
+        devs[i] = devices ? devices[i] : (transport == RT_TRANSPORT_MEMCPY ? (int)(i % (uint32_t)n_dev) : (int)i);
         if (devs[i] < 0 || devs[i] >= n_dev) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: device %d out of range", devs[i]);
-        for (uint32_t j = 0; j < i; j++)
+        for (uint32_t j = 0; j < i && transport == RT_TRANSPORT_RCCL; j++)
             if (devs[j] == devs[i]) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_create: device %d listed twice (one rank per GPU)", devs[i]);
     }
-    int rc = rccl_bind();
+    int rc = transport == RT_TRANSPORT_RCCL ? rccl_bind() : RT_OK;
     if (rc != RT_OK) return rc;
     std::unique_ptr<rt_multi_renderer> m(new rt_multi_renderer());
     m->width = cfg->width; m->height = cfg->height;
+    m->transport = transport;
     m->devices = devs;
     for (uint32_t i = 0; i < n_gpus; i++) {
         rt_render_config c = *cfg;
@@ -864,8 +930,15 @@ extern "C" int rt_multi_renderer_create(const rt_render_config* cfg, const rt_ca
         if (rc != RT_OK) return rc;
         m->parts.push_back(r);
     }
-    m->comms.assign(n_gpus, nullptr);
-    RCCL_TRY(g_rccl.CommInitAll(m->comms.data(), (int)n_gpus, devs.data()));
+    if (transport == RT_TRANSPORT_RCCL) {
+        m->comms.assign(n_gpus, nullptr);
+        RCCL_TRY(g_rccl.CommInitAll(m->comms.data(), (int)n_gpus, devs.data()));
+    }
+    m->ev_part.assign(n_gpus, nullptr);
+    for (uint32_t i = 0; i < n_gpus; i++) {
+        HIP_TRY(hipSetDevice(devs[i]));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_part[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipSetDevice(devs[0]));
     const size_t image_floats = (size_t)cfg->width * cfg->height * 4;
     HIP_TRY(m->image.alloc(image_floats * sizeof(float)));
@@ -878,33 +951,76 @@ extern "C" int rt_multi_renderer_create(const rt_render_config* cfg, const rt_ca
 
 extern "C" void rt_multi_renderer_destroy(rt_multi_renderer* m) { delete m; }
 
+// a failure between the launches and the final synchronisation must not leave work in flight on the ranks' streams
+static int multi_fail_drain(rt_multi_renderer* m, int rc) {
+    const std::string msg = rt_last_error();   // the drains below may overwrite the message of the failure we report
+    for (size_t i = 0; i < m->parts.size(); i++)
+        if (hipSetDevice(m->devices[i]) == hipSuccess) (void)hipStreamSynchronize(m->parts[i]->stream);
+    return rt_fail(rc, "%s", msg.c_str());
+}
+
 extern "C" int rt_multi_renderer_render(rt_multi_renderer* m) {
     if (!m) return rt_fail(RT_ERR_INVALID, "rt_multi_renderer_render: null renderer");
     const uint32_t n = (uint32_t)m->parts.size();
     const auto t0 = std::chrono::steady_clock::now();
+    hipStream_t s0 = m->parts[0]->stream;
     for (uint32_t i = 0; i < n; i++) {   // every GPU renders its tiles; the launches are asynchronous, so the N kernels run side by side
         int rc = rt_renderer_render_async(m->parts[i], m->parts[i]->stream, nullptr);
-        if (rc != RT_OK) return rc;
+        if (rc != RT_OK) return multi_fail_drain(m, rc);
+        HIP_TRY(hipEventRecord(m->ev_part[i], m->parts[i]->stream));
     }
+    // stream 0 waits for EVERY rank's render before the exchange timer starts: times()[2] is then exchange + assembly, not the
+    // slowest rank's tail (the receive would otherwise absorb the imbalance of the frame)
     HIP_TRY(hipSetDevice(m->devices[0]));
-    HIP_TRY(hipEventRecord(m->ev_rendered, m->parts[0]->stream));
+    for (uint32_t i = 1; i < n; i++) HIP_TRY(hipStreamWaitEvent(s0, m->ev_part[i], 0));
+    HIP_TRY(hipEventRecord(m->ev_rendered, s0));
     // the single frame-end exchange: rank i sends its shard to rank 0 (rank 0 to itself), rank 0 receives N shards in rank order.
     // With one GPU this is the degenerate self-exchange of the whole row-major frame.
     const size_t count = n > 1 ? m->parts[0]->shard_floats : (size_t)m->width * m->height * 4;
     float* dst = n > 1 ? m->gathered.as<float>() : m->image.as<float>();
-    RCCL_TRY(g_rccl.GroupStart());
-    for (uint32_t i = 0; i < n; i++) RCCL_TRY(g_rccl.Send(m->parts[i]->fb.p, count, ncclFloat, 0, m->comms[i], m->parts[i]->stream));
-    for (uint32_t i = 0; i < n; i++) RCCL_TRY(g_rccl.Recv(dst + (size_t)i * count, count, ncclFloat, (int)i, m->comms[0], m->parts[0]->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
+    if (m->transport == RT_TRANSPORT_RCCL) {
+        // an error inside the group still CLOSES the group (an open group makes the process's next collective call hang)
+        ncclResult_t first = g_rccl.GroupStart();
+        const char* what = "ncclGroupStart";
+        if (first == ncclSuccess) {
+            for (uint32_t i = 0; i < n && first == ncclSuccess; i++) {
+                first = g_rccl.Send(m->parts[i]->fb.p, count, ncclFloat, 0, m->comms[i], m->parts[i]->stream);
+                what = "ncclSend";
+            }
+            for (uint32_t i = 0; i < n && first == ncclSuccess; i++) {
+                first = g_rccl.Recv(dst + (size_t)i * count, count, ncclFloat, (int)i, m->comms[0], s0);
+                what = "ncclRecv";
+            }
+            const ncclResult_t end = g_rccl.GroupEnd();
+            if (first == ncclSuccess && end != ncclSuccess) { first = end; what = "ncclGroupEnd"; }
+        }
+        if (first != ncclSuccess) {
+            (void)rt_fail(RT_ERR_HIP, "%s failed in the frame-end exchange: %s", what, g_rccl.GetErrorString(first));
+            return multi_fail_drain(m, RT_ERR_HIP);
+        }
+    } else {
+        for (uint32_t i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(m->devices[i]));
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)i * count, m->parts[i]->fb.p, count * sizeof(float), hipMemcpyDeviceToDevice, m->parts[i]->stream));
+            HIP_TRY(hipEventRecord(m->ev_part[i], m->parts[i]->stream));
+        }
+        HIP_TRY(hipSetDevice(m->devices[0]));
+        for (uint32_t i = 1; i < n; i++) HIP_TRY(hipStreamWaitEvent(s0, m->ev_part[i], 0));
+    }
     HIP_TRY(hipSetDevice(m->devices[0]));
     if (n > 1) {
-        int rc = rt_renderer_assemble(m->parts[0], m->gathered.as<float>(), m->image.as<float>(), m->parts[0]->stream);
-        if (rc != RT_OK) return rc;
+        int rc = rt_renderer_assemble(m->parts[0], m->gathered.as<float>(), m->image.as<float>(), s0);
+        if (rc != RT_OK) return multi_fail_drain(m, rc);
     }
-    HIP_TRY(hipEventRecord(m->ev_done, m->parts[0]->stream));
+    HIP_TRY(hipEventRecord(m->ev_done, s0));
     for (uint32_t i = 0; i < n; i++) {
         HIP_TRY(hipSetDevice(m->devices[i]));
         HIP_TRY(hipStreamSynchronize(m->parts[i]->stream));
+    }
+    for (uint32_t i = 0; i < n; i++) {   // RT_TRAVERSAL_QUEUE worlds (baseline kernel): an overflowed queue is an error here too
+        HIP_TRY(hipSetDevice(m->devices[i]));
+        int rc = check_traversal_overflow(m->parts[i]->scene);
+        if (rc != RT_OK) return rc;
     }
     m->last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     m->rendered = true;

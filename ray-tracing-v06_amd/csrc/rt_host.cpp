@@ -31,7 +31,11 @@ int rt_fail(int code, const char* fmt, ...) {
     return code;
 }
 extern "C" const char* rt_last_error(void) { return g_last_error.c_str(); }
-extern "C" const char* rt_version(void) { return "rt06-amd 0.1 (gfx950)"; }
+#ifndef RT06_SRC_SHA256
+#define RT06_SRC_SHA256 "unstamped"
+#endif
+extern "C" const char* rt_version(void) { return "rt06-amd 0.3 (gfx950) src " RT06_SRC_SHA256; }
+extern "C" const char* rt_source_hash(void) { return RT06_SRC_SHA256; }
 
 // ---------------------------------------------------------------------------------------------
 // cameras — rt_engine/shaders/cu_Cameras.cuh ctors (:16-25, :40-52, :73-85)

@@ -110,7 +110,7 @@ struct StreamParams {
     uint32_t total;          // n_local_pixels * pass_spp
     uint32_t inner_keep, shade_min, leaf_min;
     uint32_t chunk;          // sample indices per work-queue fetch
-    float* samples;          // [n_local_pixels/64][pass_spp][64][3], i.e. sample index n -> floats 3n..3n+2
+    float4* samples;         // [n_local_pixels/64][pass_spp][64] radiance (x, y, z, -), i.e. slot n of sample index n: ONE aligned 16-byte store per sample
     // primary rays of the pass, written by primary_rays_kernel and consumed by sample regeneration, indexed by n:
     float4* prim_o;          // (ray origin, ray time)
     float4* prim_d;          // (ray direction, -)
@@ -314,8 +314,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #define RT_EMIT_DARK() RT_EMIT(EXT ? accum_rad.x : 0.0f, EXT ? accum_rad.y : 0.0f, EXT ? accum_rad.z : 0.0f)
 #define RT_EMIT(rx, ry, rz)                                   \
     do {                                                      \
-        float* o_ = p.samples + (size_t)out_idx * 3u;         \
-        o_[0] = (rx); o_[1] = (ry); o_[2] = (rz);             \
+        p.samples[out_idx] = make_float4((rx), (ry), (rz), 0.0f); \
         cur = K_NEED;                                    \
     } while (0)
 
@@ -766,23 +765,24 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(StreamParams p, uint3
 
 // Adds the samples of one pass to each pixel IN SAMPLE ORDER (Renderer.cu:198-204: `radiance += ...`),
 // and on the last pass applies mean / clamp / sqrt-gamma / alpha (Renderer.cu:206-216).
-__global__ __launch_bounds__(256) void resolve_kernel(StreamParams p, float* __restrict__ running, float* __restrict__ out, uint32_t last_pass) {
+__global__ __launch_bounds__(256) void resolve_kernel(StreamParams p, float4* __restrict__ running, float* __restrict__ out, uint32_t last_pass) {
     uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
     if (L >= p.tm.n_local_tiles * RT_TILE * RT_TILE) return;
     uint32_t gid;
     if (!local_pixel_to_gid(p.tm, L, gid)) return;
     f3 radiance = mk3(0.0f);
-    if (p.pass_first_s != 0u) radiance = ld3(running + (size_t)L * 3u);
-    const float* src = p.samples + ((size_t)(L >> 6) * p.pass_spp * 64u + (L & 63u)) * 3u;
+    if (p.pass_first_s != 0u) { const float4 r = running[L]; radiance = mk3(r.x, r.y, r.z); }
+    const float4* src = p.samples + ((size_t)(L >> 6) * p.pass_spp * 64u + (L & 63u));
     for (uint32_t s = 0; s < p.pass_spp; s++) {
-        radiance = radiance + ld3(src);
-        src += 64u * 3u;
+        const float4 v = *src;
+        radiance = radiance + mk3(v.x, v.y, v.z);
+        src += 64u;
     }
     if (last_pass) {
         radiance = radiance * (1.0f / (float)p.spp);
         f3 col = clamp01_sqrt(radiance);
         reinterpret_cast<float4*>(out)[p.tm.direct ? gid : L] = make_float4(col.x, col.y, col.z, 1.0f);
     } else {
-        st3(running + (size_t)L * 3u, radiance);
+        running[L] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
     }
 }

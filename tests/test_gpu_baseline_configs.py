@@ -56,14 +56,89 @@ def test_config5_geometry_3840x2160_sparse_parity_and_multi_pass(monkeypatch):
     W, H, spp, depth = 3840, 2160, 6, 50
     scene, cam = config_scene(p, "book2_final"), config_cameras(p, "book2_final", W, H)
     w = scene.getWorldPtr()
-    monkeypatch.setenv("RT06_PASS_BUDGET_BYTES", str(W * H * 12 * 2))   # two samples per pixel per pass
+    monkeypatch.setenv("RT06_PASS_SPP", "2")   # two samples per pixel per pass
     img, info = _single(p, W, H, spp, depth, cam, w)
     assert info["variant"] == 3 and not info["lds_resident"]             # the global-memory form of the streaming kernel
     assert np.isfinite(img).all() and np.all(img[..., 3] == 1.0)
     _sparse_check(img, w, cam, W, H, spp, depth, 32, 50)
-    monkeypatch.delenv("RT06_PASS_BUDGET_BYTES")
+    monkeypatch.delenv("RT06_PASS_SPP")
     one_pass, _ = _single(p, W, H, spp, depth, cam, w)
     assert one_pass.tobytes() == img.tobytes()
+
+
+def test_config5_at_its_own_resolution_with_natural_passes():
+    """configs[4] at 3840 x 2160, depth 50, with the REAL pass budget (40 GiB of per-sample buffers = 80 spp per pass at this size):
+    264 spp = 4 natural passes (80 + 80 + 80 + 24), i.e. the regime of the 10 000-spp run (125 passes) — running sums carried
+    from pass to pass, the work counter reset per pass, the per-pass buffers at their full size.  32 random pixels + the four
+    corners against the CPU oracle, bit for bit."""
+    p = pkg()
+    W, H, spp, depth = 3840, 2160, 264, 50
+    scene, cam = config_scene(p, "book2_final"), config_cameras(p, "book2_final", W, H)
+    w = scene.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    pi = r.pass_info()
+    assert pi["n_passes"] >= 3 and pi["pass_spp"] * pi["n_passes"] >= spp, pi
+    assert pi["buffer_bytes"] <= (40 << 30) + W * H * 16, pi            # the budget covers EVERY per-sample buffer of the pass
+    assert pi["pass_spp"] * W * H * pi["bytes_per_sample"] <= 40 << 30, pi
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    times = r.kernel_times()
+    total = r.last_kernel_ms()
+    r.close()
+    assert np.isfinite(img).all() and np.all(img[..., 3] == 1.0)
+    assert 0.5 * total < sum(times) <= 1.02 * total, (times, total)    # the per-kernel times cover all passes, not the last one
+    _sparse_check(img, w, cam, W, H, spp, depth, 36, 51)
+
+
+def test_natural_and_forced_pass_cuts_give_the_same_frame(monkeypatch):
+    """the same 960 x 540 x 48 frame of the Book-2 final scene in one pass, in 3 passes of 16 and in 7 passes of 7 (the last one short)"""
+    p = pkg()
+    W, H, spp, depth = 960, 540, 48, 50
+    scene, cam = config_scene(p, "book2_final"), config_cameras(p, "book2_final", W, H)
+    w = scene.getWorldPtr()
+    one, _ = _single(p, W, H, spp, depth, cam, w)
+    for per_pass in (16, 7):
+        monkeypatch.setenv("RT06_PASS_SPP", str(per_pass))
+        many, _ = _single(p, W, H, spp, depth, cam, w)
+        assert many.tobytes() == one.tobytes(), per_pass
+
+
+def test_pass_budget_counts_every_per_sample_buffer(monkeypatch):
+    """RT06_PASS_BUDGET_BYTES bounds sample buffer + primary-ray records together (it used to count 12 of 60 bytes)"""
+    p = pkg()
+    W, H, spp, depth = 640, 360, 40, 8
+    scene, cam = config_scene(p, "book1_final"), config_cameras(p, "book1_final", W, H)
+    budget = 10 << 20
+    monkeypatch.setenv("RT06_PASS_BUDGET_BYTES", str(budget))
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, scene.getWorldPtr())
+    pi = r.pass_info()
+    r.close()
+    n_px = ((W + 7) // 8) * ((H + 7) // 8) * 64
+    assert pi["n_passes"] > 1 and pi["pass_spp"] * n_px * pi["bytes_per_sample"] <= budget < (pi["pass_spp"] + 1) * n_px * pi["bytes_per_sample"], pi
+    assert pi["buffer_bytes"] == pi["pass_spp"] * n_px * pi["bytes_per_sample"] + n_px * 16, pi
+
+
+def test_kernel_times_sum_over_the_passes_of_a_render(monkeypatch):
+    """rt_renderer_kernel_times of a forced 3-pass render is about three times that of one pass of a third of the samples"""
+    p = pkg()
+    W, H, depth = 1200, 800, 50
+    scene, cam = config_scene(p, "book1_final"), config_cameras(p, "book1_final", W, H)
+    w = scene.getWorldPtr()
+
+    def stream_ms(spp):
+        r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+        n = r.pass_info()["n_passes"]
+        r.Render(); r.Render()
+        t = r.kernel_times()
+        tot = r.last_kernel_ms()
+        r.close()
+        return n, t, tot
+    n1, t1, _ = stream_ms(32)
+    monkeypatch.setenv("RT06_PASS_SPP", "32")
+    n3, t3, tot3 = stream_ms(96)
+    assert (n1, n3) == (1, 3)
+    assert 2.2 * t1[1] < t3[1] < 3.8 * t1[1], (t1, t3)
+    assert sum(t3) <= 1.02 * tot3
 
 
 @pytest.mark.parametrize("world_size", [4, 8])

@@ -455,7 +455,7 @@ def test_multi_pass_rendering_is_bit_identical(p, monkeypatch):
     r.Render()
     one = r.DownloadRenderbuffer()
     r.close()
-    monkeypatch.setenv("RT06_PASS_BUDGET_BYTES", str(W * H * 12 * 5))  # 5 samples per pixel per pass -> 8 passes
+    monkeypatch.setenv("RT06_PASS_SPP", "5")  # 5 samples per pixel per pass -> 8 passes
     r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr(), variant=2)
     r.Render()
     many = r.DownloadRenderbuffer()

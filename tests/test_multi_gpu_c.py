@@ -2,9 +2,12 @@
 
 CPU: the C-side shard layout is the one ray-tracing-v06_amd/multigpu.py and the gloo tests use, and the per-rank pixel maps
 partition the frame.  GPU (one-GPU box): the N = 1 communicator (ncclCommInitAll over one device, self send/recv inside a group)
-renders the same bits as the plain renderer, and bad device lists are refused.  N > 1 needs N GPUs: RCCL refuses two ranks on
-one device, so the 8-GPU exchange itself is exercised by the driver's scaling run only; its layout and assembly are covered
-here, by tests/test_dist_gloo.py (gloo, 2 and 3 processes) and by test_tile_sharding_is_gpu_count_invariant (N = 2, 3, 8 on one GPU)."""
+renders the same bits as the plain renderer, and bad device lists are refused.  N > 1 with RCCL needs N GPUs (RCCL refuses two
+ranks on one device), so that exchange is exercised by the driver's scaling run only — but the whole N > 1 BRANCH of
+rt_multi_renderer_* (per-rank renders side by side, shard offsets, cross-stream ordering, assemble_kernel, download) runs here
+with RT06_MULTI_TRANSPORT=memcpy, which lets 2 / 4 / 8 ranks share device 0 and moves the shards with hipMemcpyAsync on the ranks'
+own streams.  Layout and assembly are also covered by tests/test_dist_gloo.py (gloo, 2 and 3 processes) and by
+test_tile_sharding_is_gpu_count_invariant (N = 2, 3, 8 on one GPU)."""
 import numpy as np
 import pytest
 
@@ -87,3 +90,50 @@ def test_multi_renderer_over_all_gpus_of_the_box_matches_single_gpu():
     m.Render()
     assert m.DownloadRenderbuffer().tobytes() == ref.tobytes()
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which,W,H,spp,n", [("book1_final", 1200, 800, 6, 2), ("book1_final", 1200, 800, 6, 4), ("cornell_box", 600, 600, 8, 4),
+                                              ("book2_moving", 203, 117, 5, 3), ("book1_final", 1200, 800, 4, 8)])
+def test_multi_renderer_n_ranks_on_one_gpu_with_the_memcpy_transport(monkeypatch, which, W, H, spp, n):
+    """the N > 1 branch of rt_multi_renderer_render on ONE GPU: N ranks on device 0, shards moved by hipMemcpyAsync instead of
+    ncclSend / ncclRecv; the assembled frame is the single-GPU frame bit for bit, twice in a row (buffers and events are reused)"""
+    p = pkg()
+    depth = 50
+    scene, cam = config_scene(p, which), config_cameras(p, which, W, H)
+    w = scene.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    r.Render()
+    ref = r.DownloadRenderbuffer()
+    r.close()
+    monkeypatch.setenv("RT06_MULTI_TRANSPORT", "memcpy")
+    m = p.MultiRenderer.MakeRenderer(W, H, spp, depth, cam, w, n)
+    for _ in range(2):
+        m.Render()
+        img = m.DownloadRenderbuffer()
+        assert img.tobytes() == ref.tobytes()
+    total, kernels, exchange = m.times()
+    assert total > 0 and kernels > 0 and 0 <= exchange < total
+    m.close()
+
+
+@pytest.mark.gpu
+def test_multi_renderer_memcpy_transport_multi_pass_and_explicit_devices(monkeypatch):
+    """several passes per rank (running sums) under the multi-renderer, device list given explicitly with repeats"""
+    p = pkg()
+    W, H, spp, depth = 320, 200, 12, 20
+    scene, cam = config_scene(p, "book2_moving"), config_cameras(p, "book2_moving", W, H)
+    w = scene.getWorldPtr()
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
+    r.Render()
+    ref = r.DownloadRenderbuffer()
+    r.close()
+    monkeypatch.setenv("RT06_MULTI_TRANSPORT", "memcpy")
+    monkeypatch.setenv("RT06_PASS_SPP", "5")
+    m = p.MultiRenderer.MakeRenderer(W, H, spp, depth, cam, w, 3, devices=[0, 0, 0])
+    m.Render()
+    assert m.DownloadRenderbuffer().tobytes() == ref.tobytes()
+    m.close()
+    monkeypatch.setenv("RT06_MULTI_TRANSPORT", "carrier-pigeon")
+    with pytest.raises(p.capi.RtError):
+        p.MultiRenderer.MakeRenderer(W, H, spp, depth, cam, w, 2)
