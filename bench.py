@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--sparse-parity", type=int, default=36,
+                    help="N == 1: pixels of the last TIMED frame (full spp) checked against the CPU oracle after the timed region (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
@@ -216,6 +218,28 @@ def cpu_leg(args, pkg, scene, cam, gpu_image_fn):
         if nan_mismatch or not (parity["max_abs_delta"] < 1e-3):
             raise SystemExit(f"parity failed: {parity}")
     return base, counts, parity
+
+
+def sparse_leg(args, frame_rgba):
+    """Parity of the TIMED frame itself (full spp): --sparse-parity pixels (the four corners + random ones) re-rendered by the
+    CPU oracle at the full sample count and compared bit for bit.  The oracle is the checker, outside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    W, H = args.width, args.height
+    rng = np.random.default_rng(args.seed)
+    gids = rng.integers(0, W * H, max(4, args.sparse_parity)).astype(np.uint32)
+    gids[:4] = (0, W - 1, (H - 1) * W, H * W - 1)
+    oscene, ocam = make_workload(args, O, oracle=True)
+    t = time.perf_counter()
+    exp = O.render_pixels(oscene.world, ocam, W, H, args.spp, args.depth, gids, args.seed)
+    got = np.ascontiguousarray(frame_rgba.reshape(-1, 4)[gids])
+    same = (got.view(np.uint32) == exp.view(np.uint32)) | (np.isnan(got) & np.isnan(exp))
+    res = {"pixels": int(len(gids)), "spp": args.spp, "bit_identical": bool(same.all()), "mismatching_values": int((~same).sum()),
+           "max_abs_delta": float(np.nanmax(np.abs(got - exp))), "oracle_seconds": round(time.perf_counter() - t, 2),
+           "sample": "pixels of the last timed frame vs O.render_pixels at the full sample count, same seed"}
+    if not res["bit_identical"] and not (res["max_abs_delta"] < 1e-3):
+        raise SystemExit(f"full-spp sparse parity failed: {res}")
+    return res
 
 
 def main():
@@ -391,6 +415,8 @@ def main():
                 out["cpu_baseline"] = base
             if parity is not None:
                 out["parity"] = parity
+            if world_size == 1 and args.sparse_parity > 0 and not args.no_parity and args.steps > 0:
+                out["parity_timed_frame"] = sparse_leg(args, images[(frame[0] - 1) % depth].cpu().numpy())
         if args.verify_assembly and world_size > 1:
             solo = pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank, variant=args.variant)
             solo.Render()

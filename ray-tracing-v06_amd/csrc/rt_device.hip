@@ -21,6 +21,7 @@
 #include "rt_math.hpp"
 #include "rt_render_kernels.hpp"
 #include "rt_stream_kernel.hpp"
+#include "rt_xchg_kernel.hpp"
 
 #define HIP_TRY(expr)                                                                                          \
     do {                                                                                                       \
@@ -88,6 +89,7 @@ struct DeviceScene {
     bool regular_boxes = false;  // all box coordinates inside the fast-division class
     bool big = false;            // packed for the global-memory kernel (the image does not fit the LDS): 64-byte nodes, breadth-first
     bool wide = false;           // ... with 32-bit references (2^14 inner nodes / 2^15 leaf codes or more); otherwise 16-bit like the LDS image
+    bool any_moving = false;     // a MovingSphere is in the world: the leaf phase reads the second centres
 
     // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 76-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
@@ -169,8 +171,10 @@ struct DeviceScene {
         }
         float4* sph = reinterpret_cast<float4*>(host.data() + (size_t)nodes_vec4);
         float4* ext = sph + w->n_prims;
+        any_moving = false;
         for (uint32_t i = 0; i < w->n_prims; i++) {
             const rt_prim& pr = w->prims[i];
+            if (pr.mat & RT_PRIM_MOVING) any_moving = true;
             sph[i] = make_float4(pr.c0[0], pr.c0[1], pr.c0[2], pr.radius);
             uint32_t mi = pr.mat & ~RT_PRIM_MOVING;
             uint32_t moving = (pr.mat & RT_PRIM_MOVING) ? 1u : 0u;
@@ -317,6 +321,18 @@ struct DeviceScene {
     }
 };
 
+// render_kernel_xchg: did a bounded ring wait run out?  Called after a synchronisation.
+int check_xchg_error(DevBuf& flag_buf) {
+    if (!flag_buf.p) return RT_OK;
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, flag_buf.p, 4, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(flag_buf.p, 0, 4));
+        return rt_fail(RT_ERR_HIP, "render_kernel_xchg: a ring wait ran out of its bound (exchange protocol failure): the frame is incomplete");
+    }
+    return RT_OK;
+}
+
 // RT_TRAVERSAL_QUEUE: has a lane overflowed the 32-entry queue?  Called after a synchronisation.
 int check_traversal_overflow(DeviceScene& sc) {
     if (sc.dw.traversal != RT_TRAVERSAL_QUEUE) return RT_OK;
@@ -417,6 +433,9 @@ struct rt_renderer {
     uint32_t stream_blocks_per_cu = 0;
     uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
     uint32_t tune[3] = {RT_INNER_KEEP, RT_SHADE_MIN, RT_LEAF_MIN};  // scheduling thresholds of the streaming kernel
+    // render_kernel_xchg (variant 5): roles, ring capacities, population and thresholds (RT06_XCHG=tracers,extra,swap,shade,patience,prio)
+    struct { uint32_t n_tracers = 8, tq_cap = 0, sq_cap = 0, pop_extra = 192, swap_min = 16, shade_min = 48, patience = 6, prio = 1, scene_vec4 = 0, extra_in_lds = 0, keep = 44; } xc;
+    DevBuf xchg_error;           // set by the kernel when a bounded ring wait ran out (a protocol bug, never expected)
     size_t shard_floats = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -440,7 +459,7 @@ struct rt_renderer {
         n_cus = (uint32_t)prop.multiProcessorCount;
         const uint32_t lds_per_cu = 160u * 1024u;  // MI355X_MICROARCH.md: 160 KiB LDS per CU
         uint32_t want = cfg.variant;
-        if (want > 4) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
+        if (want > 5) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
         bool can_stream = scene.has_packed;
         if (can_stream) {
             stream_block = RT_STREAM_BLOCK;
@@ -465,18 +484,61 @@ struct rt_renderer {
             if (stream_lds_bytes > lds_per_cu) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
+        const bool can_xchg = can_stream && !scene.big && !scene.extended && scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes;
         if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes) ? 3u : 2u) : 1u;
+        if (want == 3 && cfg.variant == 0 && can_xchg) {
+            const char* env = std::getenv("RT06_DEFAULT_XCHG");
+            if (env && env[0] == '1') want = 5;
+        }
+        if (want == 5 && !can_xchg)
+            return rt_fail(RT_ERR_INVALID, "kernel variant 5 (ray exchange) needs an LDS-resident RT_WORLD_BVH world of the reference's feature set with box coordinates in the fast-division class");
         if (want == 4 && can_stream && scene.big)
             return rt_fail(RT_ERR_INVALID, "kernel variant 4 needs a world whose LDS image fits in 160 KiB: use variant 0, 2 or 3");
         if (want == 4 && scene.extended)
             return rt_fail(RT_ERR_INVALID, "kernel variant 4 renders the reference's feature set only (no quads / lights / constant background): use variant 0, 2 or 3");
-        if (want >= 3 && scene.dw.kind != RT_WORLD_BVH)
+        if (want >= 3 && want <= 4 && scene.dw.kind != RT_WORLD_BVH)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need an RT_WORLD_BVH world (a HittableList / bvh_node world runs on variant 2)");
         if (want >= 2 && !can_stream)
             return rt_fail(RT_ERR_INVALID, "kernel variant %u cannot take this world (its references or per-lane stacks do not fit)", want);
         if (want >= 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
+        if (variant == 5) {
+            // LDS of a workgroup (two per CU): nodes | spheres | (second centres when a sphere moves) | tracer stacks | rings
+            stream_block = RT_XCHG_BLOCK;
+            if (const char* env = std::getenv("RT06_XCHG")) {
+                unsigned v[7] = {xc.n_tracers, xc.pop_extra, xc.swap_min, xc.shade_min, xc.patience, xc.prio, xc.keep};
+                const int n = std::sscanf(env, "%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+                if (n >= 1 && v[0] >= 1 && v[0] <= RT_XCHG_BLOCK / 64 - 1) xc.n_tracers = v[0];
+                if (n >= 2 && v[1] <= 1024) xc.pop_extra = v[1];
+                if (n >= 3 && v[2] >= 1 && v[2] <= 64) xc.swap_min = v[2];
+                if (n >= 4 && v[3] >= 1 && v[3] <= 64) xc.shade_min = v[3];
+                if (n >= 5 && v[4] <= 1000) xc.patience = v[4];
+                if (n >= 6) xc.prio = v[5] ? 1u : 0u;
+                if (n >= 7 && v[6] >= 1 && v[6] <= 64) xc.keep = v[6];
+            }
+            xc.extra_in_lds = scene.any_moving ? 1u : 0u;
+            xc.scene_vec4 = scene.any_moving ? scene.packed.off_mats : scene.packed.off_extra;
+            const uint32_t fixed = xc.scene_vec4 * 16u + ((xc.n_tracers * 64u * scene.packed.stack_cap * 2u + 15u) & ~15u) + XC_WORDS * 4u;
+            static const uint32_t caps[][2] = {{128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
+            xc.tq_cap = 0;
+            for (const auto& c : caps) {
+                const uint32_t total = fixed + c[0] * (4u + XC_TQ_ENTRY_BYTES) + c[1] * (4u + XC_SQ_ENTRY_BYTES);
+                if (total <= lds_per_cu / 2u) { xc.tq_cap = c[0]; xc.sq_cap = c[1]; stream_lds_bytes = (total + 15u) & ~15u; break; }
+            }
+            if (xc.tq_cap == 0) {
+                if (cfg.variant == 5) return rt_fail(RT_ERR_INVALID, "kernel variant 5: the scene image leaves no room for the ray rings in the LDS");
+                variant = 3;   // chosen by default only: fall back to the streaming kernel
+            } else {
+                stream_blocks_per_cu = 2;
+                // the population must stay below what the places that can hold a ray add up to (no full-ring deadlock)
+                const uint32_t places = xc.n_tracers * 64u + xc.tq_cap + xc.sq_cap;
+                xc.pop_extra = std::min(xc.pop_extra, xc.tq_cap + xc.sq_cap - 16u);
+                (void)places;
+                HIP_TRY(xchg_error.alloc(4));
+                HIP_TRY(hipMemset(xchg_error.p, 0, 4));
+            }
+        }
         if ((variant == 2 || variant == 4) && !scene.big) {
             stream_block = 768;
             stream_lds_bytes = (scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u + 15u) & ~15u;
@@ -522,6 +584,7 @@ struct rt_renderer {
     }
 
     const void* stream_kernel_ptr() const {
+        if (variant == 5) return reinterpret_cast<const void*>(&render_kernel_xchg<RT_XCHG_BLOCK>);
         const bool fast = variant == 3;
         if (scene.big) {   // records in global memory: <EXACT, FILTER, BLOCK, WORLD, EXT, BIG = true, WIDE>
 #define RT_BIG_KERNEL(exact, world, ext, wide_) reinterpret_cast<const void*>(&render_kernel_stream<exact, false, 768, world, ext, true, wide_>)
@@ -619,6 +682,20 @@ struct rt_renderer {
             }
 
             void* args[] = {&p};
+            XchgParams xp;
+            if (variant == 5) {
+                if (std::getenv("RT06_XCHG")) p.inner_keep = xc.keep;
+                xp.s = p;
+                xp.n_tracers = xc.n_tracers; xp.tq_cap = xc.tq_cap; xp.sq_cap = xc.sq_cap;
+                xp.pop_target = xc.n_tracers * 64u + xc.pop_extra;
+                xp.swap_min = xc.swap_min; xp.shade_min = xc.shade_min; xp.shade_patience = xc.patience;
+                xp.scene_vec4 = xc.scene_vec4; xp.extra_in_lds = xc.extra_in_lds; xp.shader_prio = xc.prio;
+                xp.error_flag = xchg_error.as<uint32_t>();
+#ifdef RT_PHASE_TIMERS
+                xp.xphase_acc = phase_acc.as<unsigned long long>();
+#endif
+                args[0] = &xp;
+            }
             HIP_TRY(hipEventRecord(ke[1], st));
             HIP_TRY(hipLaunchKernel(stream_kernel_ptr(), dim3(grid), dim3(stream_block), args, stream_lds_bytes, st));
             HIP_TRY(hipEventRecord(ke[2], st));
@@ -633,8 +710,11 @@ struct rt_renderer {
                         std::fclose(f);
                     }
                 }
-                static const char* names[16] = {"hot inner loop", "irregular loop", "leaf phase", "shade (tail)", "regenerate", "begin trace", "(inner steps)", "loop top",
+                static const char* names_stream[16] = {"hot inner loop", "irregular loop", "leaf phase", "shade (tail)", "regenerate", "begin trace", "(inner steps)", "loop top",
                                                 "schedule check", "shade: miss/sky + hit common", "shade: dielectric prep", "shade: dielectric dir", "shade: on-unit-sphere loop", "shade: metal/lambert/checker", "-", "-"};
+                static const char* names_xchg[16] = {"T hot inner loop", "T irregular loop", "T leaf phase", "T exchange", "T idle", "-", "-", "-",
+                                                     "S wait", "S pop", "S shade", "S new samples", "S begin trace", "S push", "-", "-"};
+                const char* const* names = variant == 5 ? names_xchg : names_stream;
                 unsigned long long tot = 0;
                 for (int i = 0; i < 16; i++) tot += h[i];
                 for (int i = 0; i < 16; i++)
@@ -713,6 +793,8 @@ extern "C" int rt_renderer_render(rt_renderer* r) {
     int rc = rt_renderer_render_async(r, r->stream, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipStreamSynchronize(r->stream));
+    rc = check_xchg_error(r->xchg_error);
+    if (rc != RT_OK) return rc;
     return check_traversal_overflow(r->scene);
 }
 
@@ -772,6 +854,8 @@ extern "C" int rt_renderer_download(rt_renderer* r, float* host_rgba, size_t n_f
     if (r->timed) HIP_TRY(hipEventSynchronize(r->ev1));
     HIP_TRY(hipStreamSynchronize(r->stream));
     HIP_TRY(hipMemcpy(host_rgba, r->fb.p, need * sizeof(float), hipMemcpyDeviceToHost));
+    int rc = check_xchg_error(r->xchg_error);
+    if (rc != RT_OK) return rc;
     return check_traversal_overflow(r->scene);
 }
 
@@ -1019,7 +1103,8 @@ extern "C" int rt_multi_renderer_render(rt_multi_renderer* m) {
     }
     for (uint32_t i = 0; i < n; i++) {   // RT_TRAVERSAL_QUEUE worlds (baseline kernel): an overflowed queue is an error here too
         HIP_TRY(hipSetDevice(m->devices[i]));
-        int rc = check_traversal_overflow(m->parts[i]->scene);
+        int rc = check_xchg_error(m->parts[i]->xchg_error);
+        if (rc == RT_OK) rc = check_traversal_overflow(m->parts[i]->scene);
         if (rc != RT_OK) return rc;
     }
     m->last_total_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();

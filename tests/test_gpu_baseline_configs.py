@@ -108,7 +108,7 @@ def test_pass_budget_counts_every_per_sample_buffer(monkeypatch):
     p = pkg()
     W, H, spp, depth = 640, 360, 40, 8
     scene, cam = config_scene(p, "book1_final"), config_cameras(p, "book1_final", W, H)
-    budget = 10 << 20
+    budget = 100 << 20
     monkeypatch.setenv("RT06_PASS_BUDGET_BYTES", str(budget))
     r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, scene.getWorldPtr())
     pi = r.pass_info()
