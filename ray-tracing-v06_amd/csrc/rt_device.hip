@@ -327,8 +327,20 @@ int check_xchg_error(DevBuf& flag_buf) {
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, flag_buf.p, 4, hipMemcpyDeviceToHost));
     if (flag) {
-        HIP_TRY(hipMemset(flag_buf.p, 0, 4));
-        return rt_fail(RT_ERR_HIP, "render_kernel_xchg: a ring wait ran out of its bound (exchange protocol failure): the frame is incomplete");
+        if (std::getenv("RT06_DEBUG")) {   // what the waves that gave up saw
+            std::vector<uint32_t> h(flag_buf.bytes / 4u);
+            HIP_TRY(hipMemcpy(h.data(), flag_buf.p, flag_buf.bytes, hipMemcpyDeviceToHost));
+            int shown = 0;
+            for (size_t w = 0; 16u + (w + 1) * RT_XCHG_DEBUG_WORDS <= h.size() && shown < 60; w++) {
+                const uint32_t* o = h.data() + 16u + w * RT_XCHG_DEBUG_WORDS;
+                if (!o[0]) continue;
+                shown++;
+                fprintf(stderr, "[rt06 xchg] wg %zu wave %zu why %u: a %u b %u c %u d %u | sq h %u t %u tq h %u t %u | pop %u dry %u done %u err %u\n", w / (RT_XCHG_BLOCK / 64u),
+                        w % (RT_XCHG_BLOCK / 64u), o[0], o[1], o[2], o[3], o[4], o[5] & 0xffffu, o[5] >> 16, o[6] & 0xffffu, o[6] >> 16, o[7], o[8], o[9], o[10]);
+            }
+        }
+        HIP_TRY(hipMemset(flag_buf.p, 0, flag_buf.bytes));
+        return rt_fail(RT_ERR_HIP, "render_kernel_xchg: a wait ran out of its bound (code %u, exchange protocol failure): the frame is incomplete", flag);
     }
     return RT_OK;
 }
@@ -434,7 +446,7 @@ struct rt_renderer {
     uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
     uint32_t tune[3] = {RT_INNER_KEEP, RT_SHADE_MIN, RT_LEAF_MIN};  // scheduling thresholds of the streaming kernel
     // render_kernel_xchg (variant 5): roles, ring capacities, population and thresholds (RT06_XCHG=tracers,extra,swap,shade,patience,prio)
-    struct { uint32_t n_tracers = 8, tq_cap = 0, sq_cap = 0, pop_extra = 192, swap_min = 16, shade_min = 48, patience = 6, prio = 1, scene_vec4 = 0, extra_in_lds = 0, keep = 44; } xc;
+    struct { uint32_t n_tracers = 9, tq_cap = 0, sq_cap = 0, pop_extra = 192, swap_min = 16, shade_min = 48, patience = 6, prio = 1, scene_vec4 = 0, extra_in_lds = 0, keep = 44, shards = 1; } xc;
     DevBuf xchg_error;           // set by the kernel when a bounded ring wait ran out (a protocol bug, never expected)
     size_t shard_floats = 0;
     hipStream_t stream = nullptr;
@@ -507,8 +519,8 @@ struct rt_renderer {
             // LDS of a workgroup (two per CU): nodes | spheres | (second centres when a sphere moves) | tracer stacks | rings
             stream_block = RT_XCHG_BLOCK;
             if (const char* env = std::getenv("RT06_XCHG")) {
-                unsigned v[7] = {xc.n_tracers, xc.pop_extra, xc.swap_min, xc.shade_min, xc.patience, xc.prio, xc.keep};
-                const int n = std::sscanf(env, "%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+                unsigned v[8] = {xc.n_tracers, xc.pop_extra, xc.swap_min, xc.shade_min, xc.patience, xc.prio, xc.keep, xc.shards};
+                const int n = std::sscanf(env, "%u,%u,%u,%u,%u,%u,%u,%u", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6], &v[7]);
                 if (n >= 1 && v[0] >= 1 && v[0] <= RT_XCHG_BLOCK / 64 - 1) xc.n_tracers = v[0];
                 if (n >= 2 && v[1] <= 1024) xc.pop_extra = v[1];
                 if (n >= 3 && v[2] >= 1 && v[2] <= 64) xc.swap_min = v[2];
@@ -516,15 +528,17 @@ struct rt_renderer {
                 if (n >= 5 && v[4] <= 1000) xc.patience = v[4];
                 if (n >= 6) xc.prio = v[5] ? 1u : 0u;
                 if (n >= 7 && v[6] >= 1 && v[6] <= 64) xc.keep = v[6];
+                if (n >= 8 && (v[7] == 1 || v[7] == 2)) xc.shards = v[7];
             }
+            if (xc.shards > xc.n_tracers || xc.shards > RT_XCHG_BLOCK / 64 - xc.n_tracers) xc.shards = 1;   // every shard needs a tracer and a shader
             xc.extra_in_lds = scene.any_moving ? 1u : 0u;
             xc.scene_vec4 = scene.any_moving ? scene.packed.off_mats : scene.packed.off_extra;
-            const uint32_t fixed = xc.scene_vec4 * 16u + ((xc.n_tracers * 64u * scene.packed.stack_cap * 2u + 15u) & ~15u) + XC_WORDS * 4u;
-            static const uint32_t caps[][2] = {{128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}};
+            const uint32_t fixed = xc.scene_vec4 * 16u + ((xc.n_tracers * 64u * scene.packed.stack_cap * 2u + 15u) & ~15u) + xc.shards * XC_WORDS * 4u;
+            static const uint32_t caps[][2] = {{128, 128}, {64, 128}, {64, 64}, {32, 64}, {32, 32}, {16, 32}, {16, 16}};   // per workgroup: divided by the shards
             xc.tq_cap = 0;
             for (const auto& c : caps) {
                 const uint32_t total = fixed + c[0] * (4u + XC_TQ_ENTRY_BYTES) + c[1] * (4u + XC_SQ_ENTRY_BYTES);
-                if (total <= lds_per_cu / 2u) { xc.tq_cap = c[0]; xc.sq_cap = c[1]; stream_lds_bytes = (total + 15u) & ~15u; break; }
+                if (total <= lds_per_cu / 2u && c[0] / xc.shards >= 16u) { xc.tq_cap = c[0] / xc.shards; xc.sq_cap = c[1] / xc.shards; stream_lds_bytes = (total + 15u) & ~15u; break; }
             }
             if (xc.tq_cap == 0) {
                 if (cfg.variant == 5) return rt_fail(RT_ERR_INVALID, "kernel variant 5: the scene image leaves no room for the ray rings in the LDS");
@@ -532,11 +546,10 @@ struct rt_renderer {
             } else {
                 stream_blocks_per_cu = 2;
                 // the population must stay below what the places that can hold a ray add up to (no full-ring deadlock)
-                const uint32_t places = xc.n_tracers * 64u + xc.tq_cap + xc.sq_cap;
-                xc.pop_extra = std::min(xc.pop_extra, xc.tq_cap + xc.sq_cap - 16u);
-                (void)places;
-                HIP_TRY(xchg_error.alloc(4));
-                HIP_TRY(hipMemset(xchg_error.p, 0, 4));
+                xc.pop_extra = std::min(xc.pop_extra, xc.shards * (xc.tq_cap + xc.sq_cap - 16u));
+                const size_t err_bytes = 64u + (size_t)n_cus * 2u * (RT_XCHG_BLOCK / 64u) * RT_XCHG_DEBUG_WORDS * 4u;
+                HIP_TRY(xchg_error.alloc(err_bytes));
+                HIP_TRY(hipMemset(xchg_error.p, 0, err_bytes));
             }
         }
         if ((variant == 2 || variant == 4) && !scene.big) {
@@ -686,8 +699,8 @@ struct rt_renderer {
             if (variant == 5) {
                 if (std::getenv("RT06_XCHG")) p.inner_keep = xc.keep;
                 xp.s = p;
-                xp.n_tracers = xc.n_tracers; xp.tq_cap = xc.tq_cap; xp.sq_cap = xc.sq_cap;
-                xp.pop_target = xc.n_tracers * 64u + xc.pop_extra;
+                xp.n_tracers = xc.n_tracers; xp.n_shards = xc.shards; xp.tq_cap = xc.tq_cap; xp.sq_cap = xc.sq_cap;
+                xp.pop_extra = xc.pop_extra;
                 xp.swap_min = xc.swap_min; xp.shade_min = xc.shade_min; xp.shade_patience = xc.patience;
                 xp.scene_vec4 = xc.scene_vec4; xp.extra_in_lds = xc.extra_in_lds; xp.shader_prio = xc.prio;
                 xp.error_flag = xchg_error.as<uint32_t>();
@@ -712,11 +725,11 @@ struct rt_renderer {
                 }
                 static const char* names_stream[16] = {"hot inner loop", "irregular loop", "leaf phase", "shade (tail)", "regenerate", "begin trace", "(inner steps)", "loop top",
                                                 "schedule check", "shade: miss/sky + hit common", "shade: dielectric prep", "shade: dielectric dir", "shade: on-unit-sphere loop", "shade: metal/lambert/checker", "-", "-"};
-                static const char* names_xchg[16] = {"T hot inner loop", "T irregular loop", "T leaf phase", "T exchange", "T idle", "-", "-", "-",
-                                                     "S wait", "S pop", "S shade", "S new samples", "S begin trace", "S push", "-", "-"};
+                static const char* names_xchg[16] = {"T hot inner loop", "T irregular loop", "T leaf phase", "T exchange", "T idle", "(lanes per hot step)", "(lanes per leaf phase)", "(finished per exchange)",
+                                                     "S wait", "S pop", "S shade", "S new samples", "S begin trace", "S push", "(traces per shade round)", "-"};
                 const char* const* names = variant == 5 ? names_xchg : names_stream;
                 unsigned long long tot = 0;
-                for (int i = 0; i < 16; i++) tot += h[i];
+                for (int i = 0; i < 16; i++) if (!(variant == 5 && (i == 5 || i == 6 || i == 7 || i == 14))) tot += h[i];
                 for (int i = 0; i < 16; i++)
                     fprintf(stderr, "[phase] %-16s %6.2f %% of wave time, %12llu visits, %8.1f cycles per visit\n", names[i], 100.0 * h[i] / (double)tot, h[16 + i], h[16 + i] ? (double)h[i] / h[16 + i] : 0.0);
             }

@@ -266,8 +266,8 @@ def _render_cpu(which, W, H, spp, depth=50, seed=1984):
     return img, cnt
 
 
-VARIANTS = [1, 2, 3, 4]   # 1 = baseline wave-per-pixel, 2 = streaming LDS kernel, 3 = 2 + fast exact division, 4 = 3 + filtered predicates
-BIT_EXACT_VARIANTS = {2, 3, 4}  # the streaming path sums samples in the reference's order: image == oracle image
+VARIANTS = [1, 2, 3, 4, 5]   # 1 = baseline wave-per-pixel, 2 = streaming LDS kernel, 3 = 2 + fast exact division, 4 = 3 + filtered predicates, 5 = 3 with rays exchanged between the waves of a workgroup
+BIT_EXACT_VARIANTS = {2, 3, 4, 5}  # the streaming path sums samples in the reference's order: image == oracle image
 
 
 @pytest.mark.parametrize("variant", VARIANTS)

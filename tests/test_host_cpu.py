@@ -279,13 +279,24 @@ def test_bench_roofline_is_recomputable_from_the_committed_counter_summary():
     spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    v, src, stamp = bench.profiled_counters("render_kernel_stream")
-    assert v is not None and src.startswith("profiles/r") and stamp and len(stamp) == 64
-    stats = [r for r in csv.DictReader(open(os.path.join(ROOT, src.replace("_pmc_summary", "_kernel_stats")))) if "render_kernel_stream" in r["Name"]]
+    v, src, stamp, at_spp = None, None, None, None
+    for kernel in ("render_kernel_xchg", "render_kernel_stream"):   # whichever kernel the newest headline summary profiled
+        v, src, stamp, at_spp = bench.profiled_counters(kernel, "book1_final", 1200, 800, 500, 50)
+        newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_bench_pmc_summary.csv"))[-1]
+        if v is not None and src == f"profiles/{newest}":
+            break
+    assert v is not None and src.startswith("profiles/r") and stamp and len(stamp) == 64 and at_spp == 500
+    stats = [r for r in csv.DictReader(open(os.path.join(ROOT, src.replace("_pmc_summary", "_kernel_stats")))) if kernel in r["Name"]]
     kernel_ms = float(stats[0]["AverageNs"]) / 1e6
     roof = bench.issue_roofline(v, kernel_ms, 1024, 2.4)
     assert 0.5 < roof["frac"] <= 1.0 and 0.4 < roof["lanes_active_frac"] < 1.0 and roof["lane_weighted_frac"] < roof["frac"]
     assert abs(roof["achieved"] - v["SQ_INSTS_VALU"] / (kernel_ms * 1e-3) / 1e9) < 0.01 and roof["peak"] == 1228.8
+    # a summary of another workload, taken at another spp, is found by workload + frame size + depth and scaled to the asked spp
+    v2, src2, _, at2 = bench.profiled_counters("render_kernel_stream", "book2_final", 800, 800, 400, 40)
+    assert src2.endswith("book2_final_pmc_summary.csv") and at2 == 200
+    v200, _, _, _ = bench.profiled_counters("render_kernel_stream", "book2_final", 800, 800, 200, 40)
+    assert abs(v2["SQ_INSTS_VALU"] - 2.0 * v200["SQ_INSTS_VALU"]) < 1e-6 * v2["SQ_INSTS_VALU"]
+    assert bench.profiled_counters("render_kernel_stream", "book2_final", 800, 801, 200, 40)[0] is None
     # the bench line committed next to it carries the same kind of object
     line = json.load(open(os.path.join(ROOT, src.replace("_pmc_summary.csv", ".json"))))
     assert line["roofline"]["bound"] == "valu_issue" and line["roofline"]["frac"] <= 1.0 and line["parity"]["bit_identical"]
