@@ -459,7 +459,7 @@ struct rt_renderer {
     std::vector<hipEvent_t> kev[RT_TIMES_RING];
     uint64_t n_renders = 0;
     uint32_t n_passes = 1;
-    static constexpr uint32_t SAMPLE_BYTES = 16, PRIMARY_BYTES = 48;   // HBM per sample index of a pass: radiance (float4) + primary ray record
+    static constexpr uint32_t SAMPLE_BYTES = RT_SAMPLE_BYTES, PRIMARY_BYTES = 48;   // HBM per sample index of a pass: radiance (float4) + primary ray record
 
     // Pick the kernel variant and size the per-pass sample buffer.
     //   0 = default (the fastest validated variant), 1 = baseline wave-per-pixel kernel,

@@ -487,10 +487,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_xchg(XchgPar
                     const float t = normalize(ray.d).y * 0.5f + 0.5f;
                     const f3 sky = linear_interpolate(mk3(0.1f, 0.2f, 0.4f), mk3(0.9f, 0.9f, 0.99f), t);
                     const f3 rad = atten * sky;
-                    p.samples[out_idx] = make_float4(rad.x, rad.y, rad.z, 0.0f);
+                    store_sample(p.samples, out_idx, rad.x, rad.y, rad.z);
                     state = S_NEED;
                 } else if (depth + 1u >= p.max_depth) {
-                    p.samples[out_idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the scatter of the last allowed bounce cannot reach the sky
+                    store_sample(p.samples, out_idx, 0.0f, 0.0f, 0.0f);   // the scatter of the last allowed bounce cannot reach the sky
                     state = S_NEED;
                 } else {
                     const f3 hit_p = ray_at(ray, rec_t);
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_xchg(XchgPar
                         }
                     }
                     if (!scattered_ok) {
-                        p.samples[out_idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        store_sample(p.samples, out_idx, 0.0f, 0.0f, 0.0f);
                         state = S_NEED;
                     } else {
                         atten = atten * albedo;
@@ -588,15 +588,15 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_xchg(XchgPar
                 const uint32_t rank = lane_rank(m_need);
                 if (state == S_NEED && rank < take) {
                     const uint32_t n = pool_next + rank;
-                    const uint4 rs = p.prim_rng[n];
+                    const uint4 rs = RT_LOAD_ONCE(p.prim_rng + n);
                     if ((rs.x | rs.y | rs.z | rs.w) != 0u) {
-                        const float4 po = p.prim_o[n], pd = p.prim_d[n];
+                        const float4 po = RT_LOAD_ONCE(p.prim_o + n), pd = RT_LOAD_ONCE(p.prim_d + n);
                         out_idx = n;
                         ray.o = mk3(po.x, po.y, po.z); ray.d = mk3(pd.x, pd.y, pd.z); ray.time = po.w;
                         rng.s0 = rs.x; rng.s1 = rs.y; rng.s2 = rs.z; rng.s3 = rs.w;
                         atten = mk3(1.0f);
                         depth = 0;
-                        if (p.max_depth == 0u) p.samples[n] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // and the lane asks again
+                        if (p.max_depth == 0u) store_sample(p.samples, n, 0.0f, 0.0f, 0.0f);   // and the lane asks again
                         else state = S_RAY;
                     }
                     // a padding pixel (outside the image / past the last tile) consumes the index and the lane asks again

@@ -1,15 +1,16 @@
 #!/bin/bash
 # One gpurun call that produces everything tools/summarize_profiles.py copies into profiles/ (TAG = round, default r02):
-#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'   then   python tools/summarize_profiles.py r02
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r03'   then   python tools/summarize_profiles.py r03
 # Counters are collected in their own passes (rocprofv3 --pmc with --kernel-trace only), HBM counters one per pass, as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes.  The bench line is taken LAST, on the same box, after the counter
 # summary of this very library has been written (so its roofline is priced with counters that are not stale).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 D=gpurun_out/prof_$TAG
 rm -rf $D && mkdir -p $D
-python -c "import __graft_entry__ as G; print(G.load_package().capi.source_hash())" > $D/csrc_sha256.txt
+python -c "import __graft_entry__ as G; print(G.load_package().capi.library_hash())" > $D/csrc_sha256.txt   # the hash embedded in the loaded BINARY
+echo "book1_final 1200 800 500 50" > $D/config.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0 > $D/stats.log 2>&1
 echo "stats done"
 BENCH="python3 bench.py --steps 2 --warmup 1 --cpu-seconds 0"

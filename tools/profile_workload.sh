@@ -4,13 +4,16 @@
 # Same rules as tools/profile_round.sh: counters in their own passes (--pmc with --kernel-trace only), HBM counters one per pass;
 # plus the vector-L1 / L2 counters that say what the global-memory form of the streaming kernel waits for.
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-book2_final}
 export TMPDIR=/tmp
 D=gpurun_out/prof_${TAG}_$WL
 rm -rf $D && mkdir -p $D
-python -c "import __graft_entry__ as G; print(G.load_package().capi.source_hash())" > $D/csrc_sha256.txt
-ARGS="--workload $WL ${WL_ARGS:---spp 200}"
+python -c "import __graft_entry__ as G; print(G.load_package().capi.library_hash())" > $D/csrc_sha256.txt   # the hash embedded in the loaded BINARY
+# profiled at an spp that fits ONE pass (bench.py scales the per-launch counters to other sample counts): WL_W WL_H WL_SPP WL_DEPTH
+W=${WL_W:-3840}; H=${WL_H:-2160}; SPP=${WL_SPP:-64}; DEPTH=${WL_DEPTH:-50}
+echo "$WL $W $H $SPP $DEPTH" > $D/config.txt
+ARGS="--workload $WL --width $W --height $H --spp $SPP --depth $DEPTH"
 python bench.py $ARGS --steps 5 --warmup 1 > $D/bench.json 2> $D/bench.err
 BENCH="python3 bench.py $ARGS --steps 2 --warmup 1 --cpu-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $BENCH > $D/stats.log 2>&1

@@ -3,7 +3,7 @@
 The counter summary is stamped with the hash of the csrc sources the profiled library was built from (written on the GPU
 box by profile_round.sh), which bench.py compares with the running library (roofline.counters_stale)."""
 import collections, csv, glob, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 name = sys.argv[2] if len(sys.argv) > 2 else "bench"     # profiles/TAG_NAME_*: `bench` = the headline command
 src, out = f"gpurun_out/prof_{tag}" if name == "bench" else f"gpurun_out/prof_{tag}_{name}", "profiles"
 newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
@@ -23,6 +23,8 @@ for d in sorted(os.listdir(src)):
         rows.append([k[0], k[1], len(v), f"{sum(v)/len(v):.6g}", *meta[k]])
 with open(f"{out}/{tag}_{name}_pmc_summary.csv", "w") as fo:
     fo.write(f"# csrc_sha256: {open(f'{src}/csrc_sha256.txt').read().strip()}\n")
+    if os.path.exists(f"{src}/config.txt"):   # workload W H spp depth the counters were taken at (bench.py keys its lookup on it)
+        fo.write(f"# config: {open(f'{src}/config.txt').read().strip()}\n")
     w = csv.writer(fo)
     w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch", "grid", "workgroup", "lds_bytes", "scratch", "vgpr", "sgpr"])
     w.writerows(rows)
