@@ -121,7 +121,7 @@ def profiled_counters(kernel_substr, workload, W, H, spp, depth):
     import csv
     import glob
     legacy = {"bench": ("book1_final", 1200, 800, 500, 50), "book2_moving": ("book2_moving", 800, 800, 1000, 50),
-              "cornell_box": ("cornell_box", 600, 600, 5000, 50), "book2_final": ("book2_final", 800, 800, 200, 40)}   # rounds 1-2: no config line
+              "book2_final": ("book2_final", 800, 800, 200, 40)}   # rounds 1-2: no config line (their one-pass profiles only)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")), reverse=True):
         name = os.path.basename(path).split("_", 1)[1][:-len("_pmc_summary.csv")]
         lines = open(path).read().splitlines()

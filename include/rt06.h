@@ -298,7 +298,7 @@ int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms);
  * Synchronises on that call's end.  Streaming variants (>= 2) only.                                                       */
 int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms[3]);
 /* How a render is cut into passes: out[0] = passes per render, out[1] = samples per pixel per pass, out[2] = HBM bytes per
- * sample index of a pass (16 B radiance + 48 B primary-ray record), out[3] = bytes of the per-pass buffers this renderer
+ * sample index of a pass (12 B radiance + 48 B primary-ray record), out[3] = bytes of the per-pass buffers this renderer
  * holds (sample buffer + primary rays + running sums).  A pass is sized by a budget over ALL of those buffers: 40 GiB by
  * default, RT06_PASS_BUDGET_BYTES to change it, RT06_PASS_SPP to force the samples per pixel per pass (tests).           */
 int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]);

@@ -432,7 +432,7 @@ struct rt_renderer {
     TileMap tm{};
     DevBuf fb;
     DevBuf work_counter;
-    DevBuf samples, running;     // sample buffer of one pass (16 B per sample); running sums (16 B per pixel) when spp needs several passes
+    DevBuf samples, running;     // sample buffer of one pass (12 B per sample); running sums (16 B per pixel) when spp needs several passes
     // primary rays of one pass: 3 arrays of 16 B per sample index (origin|time, direction, RNG state).  Generated on the render's
     // own stream, before the streaming kernel: generating pass k + 1 on a second stream WHILE pass k is traced was measured and is
     // harmful (the persistent kernel ran 40 % slower with the generator's waves co-resident: 100 ms instead of 70).
@@ -565,7 +565,7 @@ struct rt_renderer {
         }
         if (variant >= 2) {
             // HBM of one pass: every sample index owns SAMPLE_BYTES of radiance + PRIMARY_BYTES of primary-ray record.  The default
-            // budget (40 GiB of the 288) gives the 1200x800x500 headline one pass (30.7 GB) and a 3840x2160 frame 80 spp per pass.
+            // budget (40 GiB of the 288) gives the 1200x800x500 headline one pass (28.8 GB) and a 3840x2160 frame 86 spp per pass.
             uint64_t budget = 40ull << 30;
             const uint64_t per_sample = SAMPLE_BYTES + PRIMARY_BYTES;
             if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // bytes of ALL per-sample buffers of a pass

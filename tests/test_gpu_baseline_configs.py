@@ -67,8 +67,8 @@ def test_config5_geometry_3840x2160_sparse_parity_and_multi_pass(monkeypatch):
 
 
 def test_config5_at_its_own_resolution_with_natural_passes():
-    """configs[4] at 3840 x 2160, depth 50, with the REAL pass budget (40 GiB of per-sample buffers = 80 spp per pass at this size):
-    264 spp = 4 natural passes (80 + 80 + 80 + 24), i.e. the regime of the 10 000-spp run (125 passes) — running sums carried
+    """configs[4] at 3840 x 2160, depth 50, with the REAL pass budget (40 GiB of per-sample buffers = 86 spp per pass at this size):
+    264 spp = 4 natural passes (86 + 86 + 86 + 6), i.e. the regime of the 10 000-spp run (117 passes) — running sums carried
     from pass to pass, the work counter reset per pass, the per-pass buffers at their full size.  32 random pixels + the four
     corners against the CPU oracle, bit for bit."""
     p = pkg()

@@ -14,7 +14,6 @@ python -c "import __graft_entry__ as G; print(G.load_package().capi.library_hash
 W=${WL_W:-3840}; H=${WL_H:-2160}; SPP=${WL_SPP:-64}; DEPTH=${WL_DEPTH:-50}
 echo "$WL $W $H $SPP $DEPTH" > $D/config.txt
 ARGS="--workload $WL --width $W --height $H --spp $SPP --depth $DEPTH"
-python bench.py $ARGS --steps 5 --warmup 1 > $D/bench.json 2> $D/bench.err
 BENCH="python3 bench.py $ARGS --steps 2 --warmup 1 --cpu-seconds 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- $BENCH > $D/stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -- $BENCH > $D/pmc_fetch.log 2>&1
@@ -23,4 +22,6 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_V
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE --output-format csv -d $D/pmcB -- $BENCH > $D/pmcB.log 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --output-format csv -d $D/pmcC -- $BENCH > $D/pmcC.log 2>&1
 echo "counters done"
+python tools/summarize_profiles.py $TAG $WL > /dev/null     # on the box: profiles/${TAG}_${WL}_pmc_summary.csv of THIS library, for the line below
+python bench.py $ARGS --steps 5 --warmup 1 > $D/bench.json 2> $D/bench.err
 cat $D/bench.json
