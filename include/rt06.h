@@ -271,8 +271,11 @@ typedef struct rt_render_config {
     uint32_t variant;             /* 0 = default (3 where the world allows it, else 2, else 1); 1 baseline wave-per-pixel kernel,
                                      2 streaming kernel with verbatim box tests (IEEE divisions), 3 = 2 + exact division without
                                      dividing (BVH worlds with box coordinates in [2^-40, 2^40)), 4 = 3 + filtered predicates
-                                     (experimental, reference features only).  Same image bits for all >= 2; worlds beyond the
-                                     LDS take the global-memory form of 2 / 3 (rt_renderer_kernel_info).                       */
+                                     (experimental, reference features only), 5 = 3 with rays exchanged between tracer and
+                                     shader waves of a workgroup through LDS rings (render_kernel_xchg; LDS-resident BVH worlds
+                                     of the reference's feature set; measured slower than 3, kept as an opt-in: DESIGN.md §14).
+                                     Same image bits for all >= 2; worlds beyond the LDS take the global-memory form of 2 / 3
+                                     (rt_renderer_kernel_info).                                                                */
 } rt_render_config;
 
 /* Renderer::MakeRenderer (Renderer.cu:31-67).  Copies the flat world and the
@@ -302,7 +305,7 @@ int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms
  * holds (sample buffer + primary rays + running sums).  A pass is sized by a budget over ALL of those buffers: 40 GiB by
  * default, RT06_PASS_BUDGET_BYTES to change it, RT06_PASS_SPP to force the samples per pixel per pass (tests).           */
 int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]);
-/* Which kernel the renderer resolved to: out[0] = variant actually used (1..4), out[1] = 1 when the scene image is
+/* Which kernel the renderer resolved to: out[0] = variant actually used (1..5), out[1] = 1 when the scene image is
  * LDS-resident (0: baseline kernel, or a world too large for the LDS, served from global memory / L2 with 32-bit
  * references), out[2] = workgroup size, out[3] = workgroups per CU.                                              */
 int rt_renderer_kernel_info(rt_renderer* r, uint32_t out[4]);
