@@ -711,9 +711,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             uint32_t rank = lane_rank(m_need);
             if (cur == K_NEED && rank < take) {
                 const uint32_t n = pool_next + rank;
+                // all three 16-byte parts of the record go out together: ONE global round trip (a padding pixel's two extra loads are wasted, rarely)
                 const uint4 rs = RT_LOAD_ONCE(p.prim_rng + n);
+                const float4 po = RT_LOAD_ONCE(p.prim_o + n), pd = RT_LOAD_ONCE(p.prim_d + n);
                 if ((rs.x | rs.y | rs.z | rs.w) != 0u) {
-                    const float4 po = RT_LOAD_ONCE(p.prim_o + n), pd = RT_LOAD_ONCE(p.prim_d + n);
                     out_idx = n;
                     ray.o = mk3(po.x, po.y, po.z); ray.d = mk3(pd.x, pd.y, pd.z); ray.time = po.w;
                     rng.s0 = rs.x; rng.s1 = rs.y; rng.s2 = rs.z; rng.s3 = rs.w;
@@ -779,8 +780,8 @@ __global__ __launch_bounds__(256) void primary_rays_kernel(StreamParams p, uint3
     if (p.cam.type == RT_CAM_DEFOCUS) {
         uint32_t stage = 0;   // 0: pixel jitter (Renderer.cu:199), 1: lens point (cu_Cameras.cuh:55), 2: done
         do {
-            const float u = rng.next() * 2.0f - 1.0f;
-            const float v = rng.next() * 2.0f - 1.0f;
+            const float u = rng.next_signed();
+            const float v = rng.next_signed();
             if (length2(u, v) < 1.0f) {
                 if (stage == 0u) { jx = u; jy = v; } else { a = u; b = v; }
                 stage++;

@@ -589,8 +589,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_xchg(XchgPar
                 if (state == S_NEED && rank < take) {
                     const uint32_t n = pool_next + rank;
                     const uint4 rs = RT_LOAD_ONCE(p.prim_rng + n);
+                    const float4 po = RT_LOAD_ONCE(p.prim_o + n), pd = RT_LOAD_ONCE(p.prim_d + n);   // together: one global round trip
                     if ((rs.x | rs.y | rs.z | rs.w) != 0u) {
-                        const float4 po = RT_LOAD_ONCE(p.prim_o + n), pd = RT_LOAD_ONCE(p.prim_d + n);
                         out_idx = n;
                         ray.o = mk3(po.x, po.y, po.z); ray.d = mk3(pd.x, pd.y, pd.z); ray.time = po.w;
                         rng.s0 = rs.x; rng.s1 = rs.y; rng.s2 = rs.z; rng.s3 = rs.w;
