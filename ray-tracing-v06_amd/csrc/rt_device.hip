@@ -490,7 +490,8 @@ struct rt_renderer {
                 n_top = top_bytes / (RT_NODE_DWORDS_BIG * 4u);
                 stream_lds_bytes = top_bytes + stacks;
             } else {
-                stream_lds_bytes = scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u;
+                // (1024-thread workgroups keep the material records in global memory: rt_stream_kernel.hpp MATS_GLOBAL)
+                stream_lds_bytes = (stream_block == 1024u ? scene.packed.off_mats : scene.packed.blob_vec4) * 16u + stream_block * scene.packed.stack_cap * 2u;
                 stream_lds_bytes = (stream_lds_bytes + 15u) & ~15u;
             }
             if (stream_lds_bytes > lds_per_cu) can_stream = false;
