@@ -673,7 +673,10 @@ struct rt_renderer {
             chunk = std::max(64u, std::min(RT_CHUNK_MAX, chunk & ~63u));
             if (const char* env = std::getenv("RT06_CHUNK")) { int v = std::atoi(env); if (v >= 64 && v <= 1024) chunk = (uint32_t)v & ~63u; }
             p.chunk = chunk;
-            HIP_TRY(hipMemsetAsync(work_counter.p, 0, 4, st));
+            // the streaming kernel's waves own their first chunk (chunk w for wave w): the counter starts behind those; the exchange
+            // kernel's shader waves draw every chunk from the counter
+            const uint64_t first_shared = variant == 5 ? 0ull : (uint64_t)n_waves * chunk;
+            HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)work_counter.p, (int)(uint32_t)std::min<uint64_t>(first_shared, 0xF0000000ull), 1, st));
 #ifdef RT_PHASE_TIMERS
             DevBuf phase_acc;
             HIP_TRY(phase_acc.alloc((32 + 96 * 16) * sizeof(unsigned long long)));

@@ -310,7 +310,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     uint32_t out_idx = 0;   // == the sample index n: the sample buffer is laid out in index order
 
     // ---- wave-uniform work pool: sample indices [pool_next, pool_end) ----------------------------------
-    uint32_t pool_next = 0, pool_end = 0;
+    // The FIRST chunk of a wave is its own (chunk number = the wave's number in the grid; the host starts the shared counter behind
+    // them): 6144 waves asking one counter at once take ~70 us (one word serves ~88 returning atomics per us), which a 1/8 shard feels.
+    uint32_t pool_next = min((blockIdx.x * (BLOCK / 64u) + wave) * p.chunk, p.total);
+    uint32_t pool_end = min(pool_next + p.chunk, p.total);
     bool pool_dry = false;
 
 // BVH.cu:59-60 / HittableList.cuh:22: root (world) box first, against rec.distance (= _MISS_DIST for a fresh

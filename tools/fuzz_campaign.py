@@ -15,7 +15,7 @@ from _common import as_oracle_camera, as_oracle_world, bits_equal
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=100)
 ap.add_argument("--first", type=int, default=0)
-ap.add_argument("--variants", action="store_true", help="pick a random kernel variant (0..4) per world; unsupported combinations are skipped")
+ap.add_argument("--variants", action="store_true", help="pick a random kernel variant (0..5) per world — variant 5 (ray exchange) with random roles / thresholds / ring pairs —, now and then a forced multi-pass cut; unsupported combinations are skipped")
 args = ap.parse_args()
 p = G.load_package()
 
@@ -79,7 +79,7 @@ def make_world(rng):
 
 fails = 0
 t0 = time.time()
-stats = {"lds": 0, "global": 0, "baseline": 0}
+stats = {"lds": 0, "global": 0, "baseline": 0, "xchg": 0}
 for seed in range(args.first, args.first + args.seeds):
     rng = np.random.default_rng(900000 + seed)
     s, kinds, builder, big = make_world(rng)
@@ -96,7 +96,14 @@ for seed in range(args.first, args.first + args.seeds):
     else:
         cam = p.MotionBlurCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H, 0.0, 1.0)
     w = s.getWorldPtr()
-    variant = int(rng.integers(0, 5)) if args.variants else 0
+    variant = int(rng.integers(0, 6)) if args.variants else 0
+    for k in ("RT06_XCHG", "RT06_PASS_SPP"):
+        os.environ.pop(k, None)
+    if args.variants and variant == 5:   # tracers, extra rays, exchange / shade thresholds, patience, priority, keep, ring pairs
+        os.environ["RT06_XCHG"] = ",".join(str(int(x)) for x in (rng.integers(1, 12), rng.integers(0, 300), rng.integers(1, 65), rng.integers(1, 65),
+                                                                   rng.integers(0, 12), rng.integers(0, 2), rng.integers(1, 65), rng.integers(1, 3)))
+    if args.variants and rng.random() < 0.15:
+        os.environ["RT06_PASS_SPP"] = str(int(rng.integers(1, 6)))
     try:
         r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w, variant=variant)
     except p.capi.RtError:
@@ -118,7 +125,7 @@ for seed in range(args.first, args.first + args.seeds):
         r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w, variant=variant)
         r.Render(); img = r.DownloadRenderbuffer(); r.close()
     ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
-    stats["baseline" if info["variant"] == 1 else ("lds" if info["lds_resident"] else "global")] += 1
+    stats["baseline" if info["variant"] == 1 else ("xchg" if info["variant"] == 5 else ("lds" if info["lds_resident"] else "global"))] += 1
     if info["variant"] == 1:
         ok = np.array_equal(np.isnan(img), np.isnan(ref)) and float(np.nanmax(np.abs(img - ref))) <= 1e-5 * max(1.0, float(np.nanmax(ref)))
     else:
