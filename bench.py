@@ -84,9 +84,10 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=0, choices=[0, 1, 2],
                     help="frames in flight: 2 renders frame k+1 on a second HIP stream while frame k drains its last paths and is gathered "
                          "(two renderers, two shard buffers; the collectives stay on one stream, in order); 1 = strictly serial; "
-                         "0 (default) = 1.  Measured: no gain on one GPU (a persistent workgroup frees its LDS only when its last wave "
-                         "ends, so the next frame cannot move in early); on several GPUs it is EXPECTED to hide the gather behind the next "
-                         "render — unmeasured: no multi-GPU hardware run has been recorded yet")
+                         "0 (default) = 1.  Measured on one GPU (round 3, non-blocking streams only): 72.8 instead of 74.7 ms per frame at N = 1 and "
+                         "10.1 instead of 10.7 ms for a 1/8 shard (tools/shard_pipeline.py) — the next frame's ray generation fills the issue slots "
+                         "and the tail of the draining frame.  Not the default: the per-kernel durations the roofline is priced with are those of "
+                         "kernels that share the GPU (the line then carries serial_render_ms_rank0 too), and no multi-GPU run has exercised it")
     ap.add_argument("--verify-assembly", dest="verify_assembly", action="store_true", default=True,
                     help="N > 1 (default on): after the timed region rank 0 renders the frame alone and requires the assembled image to be the "
                          "same bits; the JSON line carries assembly_verified")
@@ -274,7 +275,10 @@ def main():
     rs = [pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank,
                                     rank=rank, world_size=world_size, variant=args.variant) for _ in range(depth)]
     r = rs[0]
-    stream = torch.cuda.current_stream()
+    # With one frame in flight everything runs on torch's current stream.  With two, each slot renders on its own non-blocking stream and —
+    # for N > 1 — the collectives and the assembly stay on ONE further non-blocking stream, in frame order.  (The legacy default stream is
+    # kept out of it: event waits / records on it were measured to serialise the two side streams.)
+    stream = torch.cuda.current_stream() if depth == 1 else torch.cuda.Stream(device=dev)
     side = [torch.cuda.Stream(device=dev) for _ in range(depth)] if depth > 1 else [stream]
     images = [torch.zeros(H * W * 4, dtype=torch.float32, device=dev) if rank == 0 else None for _ in range(depth)]
     image = images[0]
@@ -282,6 +286,7 @@ def main():
     shards = [torch.zeros(r.shard_floats(), dtype=torch.float32, device=dev) for _ in range(depth)] if world_size > 1 else None
     rendered = [torch.cuda.Event() for _ in range(depth)]
     consumed = [torch.cuda.Event() for _ in range(depth)]
+    torch.cuda.synchronize()   # the buffers above were zeroed on the current stream
     for e in consumed:
         e.record(stream)
 
@@ -292,7 +297,8 @@ def main():
         d = frame[0] % depth
         frame[0] += 1
         sd = side[d]
-        sd.wait_event(consumed[d])            # the buffers of this slot are free again (frame k - depth was gathered / assembled)
+        if world_size > 1:
+            sd.wait_event(consumed[d])        # the buffers of this slot are free again (frame k - depth was gathered / assembled)
         e0 = e1 = None
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -302,13 +308,14 @@ def main():
         if record:
             e1.record(sd)
             kernel_events.append((e0, e1))
-        rendered[d].record(sd)
-        stream.wait_event(rendered[d])        # everything after the render stays on ONE stream, in frame order
-        if world_size > 1:
-            gathered = multigpu.gather_shards(shards[d], world_size, rank, dst=0)  # the single frame-end exchange (RCCL over xGMI)
-            if rank == 0:
-                rs[d].assemble(gathered.data_ptr(), images[d].data_ptr(), stream.cuda_stream)
-        consumed[d].record(stream)
+        if world_size > 1:                    # N == 1: a slot's renderer and image are touched by its own stream only, in order
+            rendered[d].record(sd)
+            stream.wait_event(rendered[d])    # everything after the render stays on ONE stream, in frame order
+            with torch.cuda.stream(stream):
+                gathered = multigpu.gather_shards(shards[d], world_size, rank, dst=0)  # the single frame-end exchange (RCCL over xGMI)
+                if rank == 0:
+                    rs[d].assemble(gathered.data_ptr(), images[d].data_ptr(), stream.cuda_stream)
+                consumed[d].record(stream)
 
     def fence():
         if world_size > 1:
@@ -327,6 +334,14 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    serial_ms = None
+    if depth > 1:   # for the record: the same frame strictly one at a time (rank-local render, no gather), after the timed region
+        fence()
+        ts = time.perf_counter()
+        for _ in range(3):
+            rs[0].render_async(side[0].cuda_stream, (images[0] if world_size == 1 else shards[0]).data_ptr())
+            side[0].synchronize()
+        serial_ms = (time.perf_counter() - ts) / 3 * 1e3
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in kernel_events])) if kernel_events else float("nan")
     kernel_ms_source = "HIP events around every launch of the timed region"
     # per-kernel durations of the timed steps: HIP events the renderer records on the stream its kernels run on (ring of 32 renders)
@@ -364,7 +379,7 @@ def main():
             "config": {"workload": f"{WORKLOADS[args.workload][8]}, {W}x{H}, {spp} spp, "
                                    f"max_depth {args.depth}, seed {args.seed}, {WORKLOADS[args.workload][9]}",
                        "parallelism": f"tile-shard x{world_size} + 1 RCCL gather" if world_size > 1 else "single GPU",
-                       "frames_in_flight": depth,
+                       "frames_in_flight": depth, "serial_render_ms_rank0": (None if serial_ms is None else round(serial_ms, 3)),
                        "kernel_variant": args.variant},
             "kernel_ms_per_step_rank0": round(kernel_ms, 3), "kernel_ms_source": kernel_ms_source + " (all kernels of a step)",
         }

@@ -692,9 +692,14 @@ struct rt_renderer {
                 p.prim_d = primary[pb].as<float4>() + n_pass;
                 p.prim_rng = reinterpret_cast<uint4*>(primary[pb].as<float4>() + 2 * n_pass);
             }
+            // The generator declares LDS it does not use: more than two resident persistent workgroups leave free on a CU (160 KiB - 2 x
+            // ~77 KiB).  Alone on the GPU that changes nothing.  With a SECOND frame in flight on another stream (bench.py --pipeline 2)
+            // it keeps the next frame's generator from moving in beside the persistent kernel's main phase (measured harmful) and
+            // lets it start exactly when workgroups of the draining frame exit — it fills the tail instead.
+            static const uint32_t primary_lds = [] { const char* e = std::getenv("RT06_PRIMARY_LDS"); return e ? (uint32_t)std::atoi(e) : 0u; }();
             for (uint32_t b0 = 0; b0 < tm.n_local_tiles; b0 += 65535u) {   // grid.y = 64-pixel block, at most 65535 per launch
                 const uint32_t nb = std::min(65535u, tm.n_local_tiles - b0);
-                primary_rays_kernel<<<dim3((64u * p.pass_spp + 255u) / 256u, nb), 256, 0, st>>>(p, b0);
+                primary_rays_kernel<<<dim3((64u * p.pass_spp + 255u) / 256u, nb), 256, primary_lds, st>>>(p, b0);
                 HIP_TRY(hipGetLastError());
             }
 
