@@ -141,9 +141,11 @@ typedef struct rt_world_flat {
  * STACK: the reference's live depth-first walk, near child first (BVH.cu:54-106, `_USE_PRIO_QUEUE false`) — every streaming kernel.
  * QUEUE: the distance-sorted queue the reference carries but disables (BVH.cu:17-49, :80-86): best-first over the whole frontier,
  *        with its off-by-one (`distances[head]` written after `head++`, :37-39) FIXED.  Capacity 32 (_PRIO_QUEUE_ELEM_COUNT) is
- *        checked: an overflow is RT_ERR_STACK at the next synchronising call, never silent.  Runs on the baseline kernel
- *        (variant 1) and the probes only: on the Book-1 final scene it saves 0.6 % of the box tests and costs 4.8 % more leaf
- *        tests (measured with the instrumented oracle), so no streaming variant was built for it.                        */
+ *        checked: an overflow is RT_ERR_STACK at the next synchronising call, never silent.  Renders on the streaming kernel
+ *        (variant 0 / 2: its queue mode — a lane walks its whole trace with the queue when the trace begins; the framebuffer is
+ *        the oracle's bit for bit) and on the baseline kernel (variant 1); the stack-walking variants 3-5 refuse it.  On the
+ *        Book-1 final scene it saves 0.6 % of the box tests and costs 4.8 % more leaf tests (instrumented oracle); its frontier
+ *        is one sorted list per ray, so it cannot share the wave-level hot loop: 1.29 against 5.6 Gsamples/s.  */
 enum { RT_TRAVERSAL_STACK = 0, RT_TRAVERSAL_QUEUE = 1 };
 
 enum {

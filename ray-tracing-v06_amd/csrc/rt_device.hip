@@ -90,6 +90,7 @@ struct DeviceScene {
     bool big = false;            // packed for the global-memory kernel (the image does not fit the LDS): 64-byte nodes, breadth-first
     bool wide = false;           // ... with 32-bit references (2^14 inner nodes / 2^15 leaf codes or more); otherwise 16-bit like the LDS image
     bool any_moving = false;     // a MovingSphere is in the world: the leaf phase reads the second centres
+    bool queue = false;          // RT_TRAVERSAL_QUEUE: BVH.cu:17-49's distance-sorted walk (the streaming kernel's RT_WORLD_BVH_QUEUE mode, records in global memory)
 
     // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 76-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
@@ -103,7 +104,7 @@ struct DeviceScene {
         const uint64_t n_codes64 = (uint64_t)w->n_prims * 2u + w->n_quads;
         const uint32_t n_inner_bound = w->kind == RT_WORLD_LIST ? 0u : w->n_nodes;
         const bool narrow_fits = n_codes64 < (uint64_t)RT_REF_LEAF - 1u && n_inner_bound < RT_REF_IRR;
-        wide = big && (!narrow_fits || w->kind != RT_WORLD_BVH || std::getenv("RT06_FORCE_WIDE") != nullptr);   // (tests force the 32-bit encoding)
+        wide = big && (!narrow_fits || w->kind != RT_WORLD_BVH || queue || std::getenv("RT06_FORCE_WIDE") != nullptr);   // (tests force the 32-bit encoding; the queue kernels are instantiated for it)
         const uint32_t ref_leaf = wide ? RT_REF_LEAF_BIG : RT_REF_LEAF, ref_irr = wide ? RT_REF_IRR_BIG : RT_REF_IRR;
         const uint32_t sphere_codes = w->n_prims * 2u;
         if (n_codes64 >= (wide ? 0x7ffffff0ull : (uint64_t)RT_REF_LEAF - 1u) || w->n_materials > RT_MAT_INDEX_MASK) return RT_OK;  // references would not fit
@@ -311,7 +312,8 @@ struct DeviceScene {
         dw.error_flag = error_flag.as<uint32_t>();
         // 16-bit references and an LDS-resident image when that fits (2 x 768-thread workgroups per CU want <= 80 KiB each,
         // one workgroup may take all 160 KiB); otherwise 32-bit references and the records stay in global memory / L2
-        if (w->traversal == RT_TRAVERSAL_QUEUE) { has_packed = false; return RT_OK; }   // baseline kernel and probes only (rt06.h)
+        queue = w->traversal == RT_TRAVERSAL_QUEUE;
+        if (queue) return pack(w, true);   // the queue walk reads the flat world itself; the shade phase reads the packed records from global memory
         int rc = pack(w, false);
         if (rc != RT_OK) return rc;
         const bool fits_lds = has_packed && (size_t)packed.blob_vec4 * 16u + (size_t)RT_STREAM_BLOCK * packed.stack_cap * 2u <= 160u * 1024u;
@@ -487,6 +489,7 @@ struct rt_renderer {
                 uint32_t top_bytes = budget > stacks ? budget - stacks : 0u;
                 top_bytes = std::min(top_bytes & ~63u, scene.packed.n_inner * (RT_NODE_DWORDS_BIG * 4u));
                 if (const char* env = std::getenv("RT06_TOP_NODES")) top_bytes = std::min(top_bytes, (uint32_t)std::atoi(env) * (RT_NODE_DWORDS_BIG * 4u));
+                if (scene.queue) top_bytes = 0;   // the queue walk reads the flat world's own nodes
                 n_top = top_bytes / (RT_NODE_DWORDS_BIG * 4u);
                 stream_lds_bytes = top_bytes + stacks;
             } else {
@@ -497,8 +500,10 @@ struct rt_renderer {
             if (stream_lds_bytes > lds_per_cu) can_stream = false;
             else stream_blocks_per_cu = std::min(2u, lds_per_cu / stream_lds_bytes);
         }
-        const bool can_xchg = can_stream && !scene.big && !scene.extended && scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes;
-        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes) ? 3u : 2u) : 1u;
+        const bool can_xchg = can_stream && !scene.big && !scene.extended && scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && !scene.queue;
+        if (scene.queue && want >= 3)
+            return rt_fail(RT_ERR_INVALID, "kernel variants 3 to 5 walk the tree with the stack of BVH.cu:54-106: a world with the distance-sorted queue (RT_TRAVERSAL_QUEUE) renders on variant 2 (or 0) and on the baseline kernel (1)");
+        if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && !scene.queue) ? 3u : 2u) : 1u;
         if (want == 3 && cfg.variant == 0 && can_xchg) {
             const char* env = std::getenv("RT06_DEFAULT_XCHG");
             if (env && env[0] == '1') want = 5;
@@ -600,6 +605,11 @@ struct rt_renderer {
     const void* stream_kernel_ptr() const {
         if (variant == 5) return reinterpret_cast<const void*>(&render_kernel_xchg<RT_XCHG_BLOCK>);
         const bool fast = variant == 3;
+        if (scene.queue) {   // the distance-sorted queue: one instantiation per feature level, records in global memory, 32-bit references
+            if (scene.textured) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH_QUEUE, 2, true, true>);
+            if (scene.extended) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH_QUEUE, 1, true, true>);
+            return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH_QUEUE, 0, true, true>);
+        }
         if (scene.big) {   // records in global memory: <EXACT, FILTER, BLOCK, WORLD, EXT, BIG = true, WIDE>
 #define RT_BIG_KERNEL(exact, world, ext, wide_) reinterpret_cast<const void*>(&render_kernel_stream<exact, false, 768, world, ext, true, wide_>)
             if (scene.dw.kind == RT_WORLD_LIST) return scene.textured ? RT_BIG_KERNEL(true, RT_WORLD_LIST, 2, true) : RT_BIG_KERNEL(true, RT_WORLD_LIST, 1, true);
@@ -650,6 +660,7 @@ struct rt_renderer {
         p.cam = cam;
         p.tm = tm;
         p.scene = scene.packed;
+        p.world = scene.dw;
         p.scene.n_top = scene.big ? n_top : 0u;
         p.samples = samples.as<float4>();
         p.work_counter = work_counter.as<uint32_t>();

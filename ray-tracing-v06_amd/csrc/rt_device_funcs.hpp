@@ -189,7 +189,7 @@ __device__ inline bool bvh_closest_intersection(const DeviceWorld& w, const Ray&
 // top, the nearest entry of the whole frontier is dequeued next.  The reference's enqueue writes `distances[head]` AFTER
 // `head++` (:37-39: index and distance end up in different slots); fixed here and in the oracle — same slot, then the
 // insertion sort as written.  Capacity _PRIO_QUEUE_ELEM_COUNT = 32, checked (the reference does not): overflow raises
-// *w.error_flag and ends the walk.  Baseline kernel and probes only (see RT_TRAVERSAL_QUEUE in rt06.h).
+// *w.error_flag and ends the walk.  Probes, baseline kernel and the streaming kernel's RT_WORLD_BVH_QUEUE mode (see RT_TRAVERSAL_QUEUE in rt06.h).
 __device__ inline bool bvh_closest_intersection_queue(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
     int32_t indices[RT_MAX_STACK];
     float distances[RT_MAX_STACK];

@@ -40,6 +40,7 @@
 #include "rt_internal.hpp"
 #include "rt_render_kernels.hpp"
 
+#define RT_WORLD_BVH_QUEUE 3     // internal WORLD mode of render_kernel_stream: an RT_WORLD_BVH world walked with the distance-sorted queue (RT_TRAVERSAL_QUEUE)
 #define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
 #define RT_CHUNK_MAX 768u        // sample indices a wave pulls per atomic (the host shrinks it for small frames / shards); 768 measured 0.35 ms ahead of 1024 and of 512 on config 2
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
@@ -165,6 +166,7 @@ struct StreamParams {
     float4* prim_d;          // (ray direction, -)
     uint4* prim_rng;         // the sample's RNG state after the camera's draws; all zero (never a valid state) marks a padding pixel
     uint32_t* work_counter;
+    DeviceWorld world;       // WORLD == RT_WORLD_BVH_QUEUE only: the flat world as BVH::ClosestIntersection's queue walk reads it (BVH.cu:17-49, :80-86)
 #ifdef RT_PHASE_TIMERS
     unsigned long long* phase_acc;  // development build only: [0..15] cycles per phase, [16..31] visits (summed over waves)
 #endif
@@ -251,7 +253,11 @@ __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const
 //                for near-ties; sound and bit-identical, but not faster yet because ~1.5 % of visits are ties.
 // WORLD: RT_WORLD_BVH (default), RT_WORLD_LIST (HittableList: bounds pre-test, then every sphere in order;
 //        a reference is RT_REF_LEAF | primitive index and the "traversal" is the leaf phase alone) or
-//        RT_WORLD_NODE_TREE (bvh_node: a node is tested against ITS OWN box when visited, then left, then right).
+//        RT_WORLD_NODE_TREE (bvh_node: a node is tested against ITS OWN box when visited, then left, then right), or
+//        RT_WORLD_BVH_QUEUE (the reference's disabled distance-sorted queue, BVH.cu:17-49: the frontier is one sorted list per ray, so
+//        there is no wave-level hot loop to share — a lane walks its whole trace when the trace begins (bvh_closest_intersection_queue,
+//        the function the probes and the baseline kernel run) and joins the others again at the shade phase; what the streaming kernel
+//        adds for such a world is the in-order resolve, i.e. a framebuffer bit-identical to the oracle's, and the sample streaming).
 // EXT >= 1: the scene uses features the reference does not have (quads, diffuse lights, a constant background, constant
 //        media; EXT = 2 adds the two textured materials — Perlin marble and the image texture — whose code is large enough
 //        to cost the other kernels registers):
@@ -338,6 +344,18 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     do {                                                                   \
         rec_t = RT_MISS_DIST;                                              \
         rec_code = -1;                                                     \
+        if (WORLD == RT_WORLD_BVH_QUEUE) {   /* the whole trace, by this lane alone; leaf code as the shade phase wants it */ \
+            HitRec qrec_;                                                  \
+            qrec_.distance = RT_MISS_DIST; qrec_.normal = mk3(0.0f); qrec_.prim = -1; qrec_.mat = 0; \
+            if (bvh_closest_intersection_queue(p.world, ray, qrec_, &rng)) { \
+                const uint32_t qp_ = (uint32_t)qrec_.prim;                 \
+                rec_t = qrec_.distance;                                    \
+                rec_code = qp_ < p.scene.n_prims ? (int32_t)(qp_ * 2u + ((p.world.prims[qp_].mat & RT_PRIM_MOVING) ? 1u : 0u)) \
+                                                 : (int32_t)(p.scene.sphere_codes + (qp_ - p.scene.n_prims)); \
+            }                                                              \
+            cur = K_SHADE;                                                 \
+            break;                                                         \
+        }                                                                  \
         ray_a = dot(ray.d, ray.d);                                         \
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 irr_pending = __ballot(!regular && (cur < K_SHADE)) != 0ull;
             }
             RT_PT(1);
-        } else {
+        } else if (WORLD != RT_WORLD_BVH_QUEUE) {   // (a queue world's lanes are never "at a node": their trace ran when it began)
             bool at_inner = cur < K_LEAF;
             uint64_t m_inner = __ballot(at_inner);
             while (m_inner != 0ull) {
@@ -525,7 +543,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 
         // ================= phase 2: leaves (BVH.cu:69-73 -> SphereHittable.cu:56-66 / :91-102) ========
         {
-            bool at_leaf = (cur - K_LEAF) < (K_SHADE - K_LEAF);
+            bool at_leaf = WORLD != RT_WORLD_BVH_QUEUE && (cur - K_LEAF) < (K_SHADE - K_LEAF);
             uint64_t m_leaf = __ballot(at_leaf);
             if (m_leaf != 0ull && ((uint32_t)__popcll(m_leaf) >= p.leaf_min || __ballot(cur < K_LEAF) == 0ull)) {
                 if (at_leaf) {

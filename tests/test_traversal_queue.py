@@ -113,21 +113,62 @@ def test_queue_traversal_on_the_gpu_matches_the_oracle_bit_for_bit(which):
 
 
 @pytest.mark.gpu
-def test_queue_traversal_renders_on_the_baseline_kernel_only():
+@pytest.mark.parametrize("which,W,H,spp", [("book1_final", 120, 80, 8), ("book2_moving", 96, 64, 9), ("cornell_box", 72, 72, 12), ("book2_final", 64, 40, 6)])
+def test_queue_traversal_renders_on_the_streaming_kernel_bit_for_bit(which, W, H, spp):
+    """round 3: a RT_TRAVERSAL_QUEUE world renders on the streaming kernel (its RT_WORLD_BVH_QUEUE mode: every lane walks its trace with the
+    distance-sorted queue when the trace begins, the samples are resolved in order): the framebuffer IS the oracle's; the baseline kernel
+    (variant 1) still takes it, up to the summation order; the stack-walking variants refuse it"""
     p = pkg()
-    W, H, spp = 120, 80, 8
-    s = config_scene(p, "book1_final").set_traversal(1)
-    cam = config_cameras(p, "book1_final", W, H)
+    s = config_scene(p, which).set_traversal(1)
+    cam = config_cameras(p, which, W, H)
     w = s.getWorldPtr()
     r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, w)
-    assert r.kernel_info()["variant"] == 1
+    info = r.kernel_info()
+    assert info["variant"] == 2 and not info["lds_resident"]
     r.Render()
     img = r.DownloadRenderbuffer()
     r.close()
     ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, 50)
-    assert np.nanmax(np.abs(img - ref)) < 1e-5      # the baseline kernel sums a pixel's samples in another order (<= 3e-7 measured)
-    with pytest.raises(p.capi.RtError):
-        p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, variant=3)
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, variant=1)
+    r.Render()
+    base = r.DownloadRenderbuffer()
+    r.close()
+    assert np.nanmax(np.abs(base - ref)) < 1e-5 * max(1.0, float(np.nanmax(ref)))      # the baseline kernel sums a pixel's samples in another order
+    for variant in (3, 4, 5):
+        with pytest.raises(p.capi.RtError):
+            p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, variant=variant)
+
+
+@pytest.mark.gpu
+def test_queue_traversal_streaming_multi_pass_and_sharded(monkeypatch):
+    import torch
+    p = pkg()
+    W, H, spp = 203, 117, 10
+    s = config_scene(p, "book1_final").set_traversal(1)
+    cam = config_cameras(p, "book1_final", W, H)
+    w = s.getWorldPtr()
+    ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, 50)
+    monkeypatch.setenv("RT06_PASS_SPP", "4")
+    r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, w)
+    r.Render()
+    assert bits_equal(r.DownloadRenderbuffer(), ref)
+    r.close()
+    shards, last = [], None
+    for rank in range(2):
+        r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, w, rank=rank, world_size=2)
+        buf = torch.zeros(r.shard_floats(), dtype=torch.float32, device="cuda:0")
+        r.render_async(torch.cuda.current_stream().cuda_stream, buf.data_ptr())
+        torch.cuda.synchronize()
+        shards.append(buf)
+        if last is not None:
+            last.close()
+        last = r
+    image = torch.empty(H * W * 4, dtype=torch.float32, device="cuda:0")
+    last.assemble(torch.cat(shards).data_ptr(), image.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    last.close()
+    assert bits_equal(image.cpu().numpy().reshape(H, W, 4), ref)
 
 
 @pytest.mark.gpu
@@ -138,6 +179,14 @@ def test_queue_overflow_is_reported_by_the_gpu_never_silent():
     with pytest.raises(p.capi.RtError) as e:
         p.api.probe_trace(w, rays)
     assert e.value.code == 4 and "queue" in str(e.value)
+    # the same through the renderer (streaming kernel, queue mode): Render() reports the overflow
+    cam = p.PinholeCamera((-10, 0, 0), (0, 0, 0), (0, 1, 0), 20.0, 1.0)
+    r = p.Renderer.MakeRenderer(32, 32, 2, 8, cam, w)
+    assert r.kernel_info()["variant"] == 2
+    with pytest.raises(p.capi.RtError) as e:
+        r.Render()
+    assert e.value.code == 4
+    r.close()
     w.traversal = 0
     hit, t, prim, _ = p.api.probe_trace(w, rays)
     assert hit.all() and (prim == 0).all()
