@@ -134,7 +134,7 @@ typedef struct rt_world_flat {
     const rt_perlin* perlin;     /* RT_MAT_LAMBERTIAN_NOISE: the world's noise tables, or NULL                            */
     const uint8_t*   image;      /* image_width * image_height * 3 bytes, or NULL                                         */
     uint32_t image_height;
-    uint32_t traversal;          /* RT_WORLD_BVH only: RT_TRAVERSAL_STACK (0, the live path) or RT_TRAVERSAL_QUEUE (1)             */
+    uint32_t traversal;          /* RT_WORLD_BVH only: RT_TRAVERSAL_STACK (0, the live path), RT_TRAVERSAL_QUEUE (1) or RT_TRAVERSAL_WIDE4 (2) */
 } rt_world_flat;                 /* 128 B */
 
 /* How BVH::ClosestIntersection walks the tree (rt_scene_set_traversal).
@@ -145,8 +145,13 @@ typedef struct rt_world_flat {
  *        (variant 0 / 2: its queue mode — a lane walks its whole trace with the queue when the trace begins; the framebuffer is
  *        the oracle's bit for bit) and on the baseline kernel (variant 1); the stack-walking variants 3-5 refuse it.  On the
  *        Book-1 final scene it saves 0.6 % of the box tests and costs 4.8 % more leaf tests (instrumented oracle); its frontier
- *        is one sorted list per ray, so it cannot share the wave-level hot loop: 1.29 against 5.6 Gsamples/s.  */
-enum { RT_TRAVERSAL_STACK = 0, RT_TRAVERSAL_QUEUE = 1 };
+ *        is one sorted list per ray, so it cannot share the wave-level hot loop: 1.29 against 5.6 Gsamples/s.
+ * WIDE4: a 4-wide walk of the SAME binary tree (not in the reference, whose nodes are binary, BVH.cuh:16-25): a visit looks
+ *        two levels down — up to four grandchild boxes, tested against rec.distance, nearest first, pushed far-to-near, culling at push time
+ *        only (BVH.cu:87-96's rule generalised); the intermediate children's boxes are not tested.  Its 32 entries (at most 3 * ceil(depth / 2) + 1
+ *        are needed) are checked like the queue's: RT_ERR_STACK at the next synchronising call.  Oracle twin: orc_world.traversal == 2.  Renders where the queue renders (streaming kernel's
+ *        lane-walk mode bit-identical to the oracle, baseline kernel); measured next to the binary walk in DESIGN.md §14.               */
+enum { RT_TRAVERSAL_STACK = 0, RT_TRAVERSAL_QUEUE = 1, RT_TRAVERSAL_WIDE4 = 2 };
 
 enum {
     RT_CAM_PINHOLE = 0,  /* PinholeCamera     cu_Cameras.cuh:12-31 */
@@ -201,7 +206,7 @@ int rt_scene_prim_bounds(const rt_scene* s, int32_t prim, float out_min[3], floa
 int rt_scene_add_quad(rt_scene* s, const float Q[3], const float u[3], const float v[3], int32_t mat, int32_t* out_quad);
 /* camera::background of "The Next Week": mode 0 = the reference's sky gradient, 1 = constant colour       */
 int rt_scene_set_background(rt_scene* s, uint32_t mode, const float color[3]);
-/* selects RT_TRAVERSAL_STACK / RT_TRAVERSAL_QUEUE for the BVH world of this scene (see the enum)                 */
+/* selects RT_TRAVERSAL_STACK / RT_TRAVERSAL_QUEUE / RT_TRAVERSAL_WIDE4 for the BVH world of this scene (see the enum) */
 int rt_scene_set_traversal(rt_scene* s, uint32_t mode);
 /* perlin::perlin() of "The Next Week": 256 random unit vectors + three Fisher-Yates permutations, drawn from the
  * build's host stream (rt_host_uniforms, stream id 0x9E81) with this seed                                  */

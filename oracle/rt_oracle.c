@@ -457,6 +457,55 @@ static int bvh_closest_intersection_queue(const orc_world* w, const ray_t* ray, 
     return hit_any;
 }
 
+/* A 4-WIDE walk of the same binary tree ("wider (BVH4/8) nodes"; the reference has binary nodes only, BVH.cuh:16-25):
+ * orc_world.traversal == 2.  A visit of an inner node looks TWO levels down: its candidates are the children of its children (a child that is
+ * a leaf stands for itself), i.e. up to four boxes; each is tested against rec.distance as it is now (BVH.cu:87-88's rule), the candidates are
+ * ordered nearest first (stable insertion sort on the entry distances, a missed box keeps _MISS_DIST) and pushed far-to-near iff
+ * `dist < rec.distance` (BVH.cu:95-96: culling at push time only).  The intermediate children's own boxes are never tested.  An alternative
+ * traversal, NOT the live path: like the queue it may differ from the stack walk in rounding near-ties.  The stack holds 32 entries
+ * (BVH.cu:17); a visit pushes up to four, so a tree of depth d needs at most 3 * ceil(d / 2) + 1: error 4 beyond. */
+static int bvh_closest_intersection_wide4(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err, rng_t* g) {
+    int32_t stack[ORC_STACK];
+    int head = 0;
+    const orc_node* nodes = w->nodes;
+    float root_dist;
+    if (!node_box(&nodes[w->root], ray, rec->distance, &root_dist, cnt)) return 0;
+    stack[head++] = w->root;
+    if ((uint32_t)head > cnt->max_stack) cnt->max_stack = head;
+    int hit_any = 0;
+    while (head != 0) {
+        const int32_t idx = stack[--head];
+        const orc_node* node = &nodes[idx];
+        if (node->left == -1) {
+            hit_any |= any_prim_closest_intersection(w, node->right, ray, rec, cnt, g);
+            continue;
+        }
+        int32_t cand[4];
+        float dist[4];
+        int n = 0;
+        const int32_t kids[2] = {node->left, node->right};
+        for (int k = 0; k < 2; k++) {
+            const orc_node* c = &nodes[kids[k]];
+            if (c->left == -1) cand[n++] = kids[k];
+            else { cand[n++] = c->left; cand[n++] = c->right; }
+        }
+        for (int i = 0; i < n; i++) {
+            dist[i] = ORC_MISS_DIST;
+            node_box(&nodes[cand[i]], ray, rec->distance, &dist[i], cnt);
+        }
+        for (int i = 1; i < n; i++)   /* nearest first; equal distances keep their order */
+            for (int j = i; j >= 1 && dist[j - 1] > dist[j]; j--) {
+                float td = dist[j]; dist[j] = dist[j - 1]; dist[j - 1] = td;
+                int32_t ti = cand[j]; cand[j] = cand[j - 1]; cand[j - 1] = ti;
+            }
+        if (head + n > ORC_STACK) { *err = 4; return hit_any; }
+        for (int i = n - 1; i >= 0; i--)
+            if (dist[i] < rec->distance) stack[head++] = cand[i];
+        if ((uint32_t)head > cnt->max_stack) cnt->max_stack = head;
+    }
+    return hit_any;
+}
+
 /* HittableList::ClosestIntersection, …/geometry/HittableList.cuh:21-34 */
 static int list_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, rng_t* g) {
     float d;
@@ -485,7 +534,8 @@ static int tree_closest_intersection(const orc_world* w, int32_t ref, const ray_
 static inline int world_closest_intersection(const orc_world* w, const ray_t* ray, rec_t* rec, orc_counters* cnt, int* err, rng_t* g) {
     cnt->rays++;
     switch (w->kind) {
-    case 0: return w->traversal == 1u ? bvh_closest_intersection_queue(w, ray, rec, cnt, err, g) : bvh_closest_intersection(w, ray, rec, cnt, err, g);
+    case 0: return w->traversal == 1u ? bvh_closest_intersection_queue(w, ray, rec, cnt, err, g)
+                 : w->traversal == 2u ? bvh_closest_intersection_wide4(w, ray, rec, cnt, err, g) : bvh_closest_intersection(w, ray, rec, cnt, err, g);
     case 1: return list_closest_intersection(w, ray, rec, cnt, g);
     default: return tree_closest_intersection(w, w->root, ray, rec, cnt, 0, err, g);
     }

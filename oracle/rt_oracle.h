@@ -63,7 +63,7 @@ typedef struct {
     const struct orc_perlin* perlin;
     const uint8_t* image;
     uint32_t image_height;
-    uint32_t traversal;         /* BVH worlds: 0 = the live depth-first stack (BVH.cu:54-106), 1 = the reference's disabled distance-sorted queue (BVH.cu:17-49), off-by-one fixed */
+    uint32_t traversal;         /* BVH worlds: 0 = the live depth-first stack (BVH.cu:54-106), 1 = the reference's disabled distance-sorted queue (BVH.cu:17-49), off-by-one fixed, 2 = a 4-wide walk of the same tree (two levels per visit) */
 } orc_world;
 /* perlin::randvec / perm_x,y,z of "The Next Week" */
 typedef struct orc_perlin { float randvec[256][3]; int32_t perm[3][256]; } orc_perlin;

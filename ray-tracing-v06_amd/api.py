@@ -197,7 +197,8 @@ class Scene:
         return self
 
     def set_traversal(self, mode):
-        """0 = the live depth-first stack (BVH.cu:54-106), 1 = the reference's disabled distance-sorted queue (BVH.cu:17-49), fixed"""
+        """0 = the live depth-first stack (BVH.cu:54-106), 1 = the reference's disabled distance-sorted queue (BVH.cu:17-49), fixed,
+        2 = a 4-wide walk of the same tree (two levels per visit; not in the reference)"""
         check(lib().rt_scene_set_traversal(self.h, mode))
         return self
 

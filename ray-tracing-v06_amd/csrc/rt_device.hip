@@ -224,8 +224,8 @@ struct DeviceScene {
         if ((w->n_prims == 0 || !w->prims) && (w->n_quads == 0 || !w->quads)) return rt_fail(RT_ERR_INVALID, "world has no primitives");
         if ((w->n_prims && !w->prims) || (w->n_quads && !w->quads)) return rt_fail(RT_ERR_INVALID, "world primitive array is null");
         if (w->background > 1) return rt_fail(RT_ERR_INVALID, "unknown background mode %u", w->background);
-        if (w->traversal > RT_TRAVERSAL_QUEUE || (w->traversal != RT_TRAVERSAL_STACK && w->kind != RT_WORLD_BVH))
-            return rt_fail(RT_ERR_INVALID, "traversal mode %u: the distance-sorted queue belongs to RT_WORLD_BVH worlds", w->traversal);
+        if (w->traversal > RT_TRAVERSAL_WIDE4 || (w->traversal != RT_TRAVERSAL_STACK && w->kind != RT_WORLD_BVH))
+            return rt_fail(RT_ERR_INVALID, "traversal mode %u: the distance-sorted queue and the 4-wide walk belong to RT_WORLD_BVH worlds", w->traversal);
         if (w->n_quads && w->kind == RT_WORLD_NODE_TREE) return rt_fail(RT_ERR_INVALID, "bvh_node trees take spheres only");
         const uint32_t n_all = w->n_prims + w->n_quads;
         if (w->n_materials == 0 || !w->materials) return rt_fail(RT_ERR_INVALID, "world has no materials");
@@ -312,7 +312,7 @@ struct DeviceScene {
         dw.error_flag = error_flag.as<uint32_t>();
         // 16-bit references and an LDS-resident image when that fits (2 x 768-thread workgroups per CU want <= 80 KiB each,
         // one workgroup may take all 160 KiB); otherwise 32-bit references and the records stay in global memory / L2
-        queue = w->traversal == RT_TRAVERSAL_QUEUE;
+        queue = w->traversal != RT_TRAVERSAL_STACK;   // the queue or the 4-wide walk: every lane walks its trace on its own
         if (queue) return pack(w, true);   // the queue walk reads the flat world itself; the shade phase reads the packed records from global memory
         int rc = pack(w, false);
         if (rc != RT_OK) return rc;
@@ -349,12 +349,13 @@ int check_xchg_error(DevBuf& flag_buf) {
 
 // RT_TRAVERSAL_QUEUE: has a lane overflowed the 32-entry queue?  Called after a synchronisation.
 int check_traversal_overflow(DeviceScene& sc) {
-    if (sc.dw.traversal != RT_TRAVERSAL_QUEUE) return RT_OK;
+    if (sc.dw.traversal == RT_TRAVERSAL_STACK) return RT_OK;
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, sc.error_flag.p, 4, hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(hipMemset(sc.error_flag.p, 0, 4));
-        return rt_fail(RT_ERR_STACK, "the distance-sorted traversal queue overflowed its %d entries (_PRIO_QUEUE_ELEM_COUNT, BVH.cu:17): the results are incomplete", RT_MAX_STACK);
+        return rt_fail(RT_ERR_STACK, "the %s overflowed its %d entries (BVH.cu:17): the results are incomplete",
+                       sc.dw.traversal == RT_TRAVERSAL_QUEUE ? "distance-sorted traversal queue" : "stack of the 4-wide walk", RT_MAX_STACK);
     }
     return RT_OK;
 }

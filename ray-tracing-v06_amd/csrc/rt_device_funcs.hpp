@@ -223,6 +223,50 @@ __device__ inline bool bvh_closest_intersection_queue(const DeviceWorld& w, cons
     return hit_any;
 }
 
+// A 4-wide walk of the same binary tree (RT_TRAVERSAL_WIDE4; SURVEY §8f rank 4 — the reference has binary nodes only, BVH.cuh:16-25): a visit
+// looks two levels down — the children of the node's children, a leaf child standing for itself: up to four boxes —, tests each against
+// rec.distance (BVH.cu:87-88), orders them nearest first (stable, a missed box keeps _MISS_DIST) and pushes them far-to-near iff
+// dist < rec.distance (BVH.cu:95-96).  The oracle's bvh_closest_intersection_wide4, statement by statement.  Overflow of the 32 entries
+// raises *w.error_flag and ends the walk (at most 3 * ceil(depth / 2) + 1 entries are ever needed).
+__device__ inline bool bvh_closest_intersection_wide4(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
+    int32_t stack[RT_MAX_STACK];
+    int head = 0;
+    float root_dist;
+    if (!node_box(w.nodes[w.root], ray, rec.distance, root_dist)) return false;
+    stack[head++] = w.root;
+    bool hit_any = false;
+    while (head != 0) {
+        const int32_t idx = stack[--head];
+        const rt_bvh_node& node = w.nodes[idx];
+        if (node.left == -1) {
+            hit_any |= any_prim_closest_intersection(w, node.right, ray, rec, rng);
+            continue;
+        }
+        int32_t cand[4];
+        float dist[4];
+        int n = 0;
+        const int32_t kids[2] = {node.left, node.right};
+        for (int k = 0; k < 2; k++) {
+            const rt_bvh_node& c = w.nodes[kids[k]];
+            if (c.left == -1) cand[n++] = kids[k];
+            else { cand[n++] = c.left; cand[n++] = c.right; }
+        }
+        for (int i = 0; i < n; i++) {
+            dist[i] = RT_MISS_DIST;
+            node_box(w.nodes[cand[i]], ray, rec.distance, dist[i]);
+        }
+        for (int i = 1; i < n; i++)
+            for (int j = i; j >= 1 && dist[j - 1] > dist[j]; j--) {
+                const float td = dist[j]; dist[j] = dist[j - 1]; dist[j - 1] = td;
+                const int32_t ti = cand[j]; cand[j] = cand[j - 1]; cand[j - 1] = ti;
+            }
+        if (head + n > RT_MAX_STACK) { *w.error_flag = 1u; return hit_any; }
+        for (int i = n - 1; i >= 0; i--)
+            if (dist[i] < rec.distance) stack[head++] = cand[i];
+    }
+    return hit_any;
+}
+
 // HittableList::ClosestIntersection, rt_engine/geometry/HittableList.cuh:21-34
 __device__ inline bool list_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
     float d;
@@ -259,7 +303,9 @@ __device__ inline bool tree_closest_intersection(const DeviceWorld& w, const Ray
 
 // rng: drawn from by constant media only (one uniform per test that enters the boundary)
 __device__ inline bool world_closest_intersection(const DeviceWorld& w, const Ray& ray, HitRec& rec, Rng* rng) {
-    if (w.kind == RT_WORLD_BVH) return w.traversal == RT_TRAVERSAL_QUEUE ? bvh_closest_intersection_queue(w, ray, rec, rng) : bvh_closest_intersection(w, ray, rec, rng);
+    if (w.kind == RT_WORLD_BVH)
+        return w.traversal == RT_TRAVERSAL_QUEUE ? bvh_closest_intersection_queue(w, ray, rec, rng)
+             : w.traversal == RT_TRAVERSAL_WIDE4 ? bvh_closest_intersection_wide4(w, ray, rec, rng) : bvh_closest_intersection(w, ray, rec, rng);
     if (w.kind == RT_WORLD_LIST) return list_closest_intersection(w, ray, rec, rng);
     return tree_closest_intersection(w, ray, rec, rng);
 }

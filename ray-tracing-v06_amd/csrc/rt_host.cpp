@@ -248,7 +248,7 @@ extern "C" int rt_scene_set_background(rt_scene* s, uint32_t mode, const float c
 
 extern "C" int rt_scene_set_traversal(rt_scene* s, uint32_t mode) {
     if (!s) return rt_fail(RT_ERR_INVALID, "rt_scene_set_traversal: null scene");
-    if (mode > RT_TRAVERSAL_QUEUE) return rt_fail(RT_ERR_INVALID, "rt_scene_set_traversal: unknown mode %u", mode);
+    if (mode > RT_TRAVERSAL_WIDE4) return rt_fail(RT_ERR_INVALID, "rt_scene_set_traversal: unknown mode %u", mode);
     s->traversal = mode;
     return RT_OK;
 }

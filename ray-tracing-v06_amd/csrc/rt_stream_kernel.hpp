@@ -40,7 +40,7 @@
 #include "rt_internal.hpp"
 #include "rt_render_kernels.hpp"
 
-#define RT_WORLD_BVH_QUEUE 3     // internal WORLD mode of render_kernel_stream: an RT_WORLD_BVH world walked with the distance-sorted queue (RT_TRAVERSAL_QUEUE)
+#define RT_WORLD_BVH_QUEUE 3     // internal WORLD mode of render_kernel_stream: an RT_WORLD_BVH world walked by each lane on its own — the distance-sorted queue (RT_TRAVERSAL_QUEUE) or the 4-wide walk (RT_TRAVERSAL_WIDE4)
 #define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
 #define RT_CHUNK_MAX 768u        // sample indices a wave pulls per atomic (the host shrinks it for small frames / shards); 768 measured 0.35 ms ahead of 1024 and of 512 on config 2
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (WORLD == RT_WORLD_BVH_QUEUE) {   /* the whole trace, by this lane alone; leaf code as the shade phase wants it */ \
             HitRec qrec_;                                                  \
             qrec_.distance = RT_MISS_DIST; qrec_.normal = mk3(0.0f); qrec_.prim = -1; qrec_.mat = 0; \
-            if (bvh_closest_intersection_queue(p.world, ray, qrec_, &rng)) { \
+            if (p.world.traversal == RT_TRAVERSAL_WIDE4 ? bvh_closest_intersection_wide4(p.world, ray, qrec_, &rng) \
+                                                         : bvh_closest_intersection_queue(p.world, ray, qrec_, &rng)) { \
                 const uint32_t qp_ = (uint32_t)qrec_.prim;                 \
                 rec_t = qrec_.distance;                                    \
                 rec_code = qp_ < p.scene.n_prims ? (int32_t)(qp_ * 2u + ((p.world.prims[qp_].mat & RT_PRIM_MOVING) ? 1u : 0u)) \

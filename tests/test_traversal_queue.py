@@ -3,7 +3,10 @@ opt-in traversal of BVH worlds (rt_scene_set_traversal / rt_world_flat.traversal
 off-by-one (`distances[head]` written after `head++`, :37-39) fixed in oracle and kernels alike.  Best-first instead of
 depth-first: on the Book-1 final scene it saves 0.6 % of the box tests and costs 4.8 % more sphere tests (first test below), which
 is why it exists on the baseline kernel and the probes only.  Parity: GPU against the oracle, bit for bit; nothing of the
-reference executes here (BVH.cu does not build in this image), so like the live traversal it is parity-unpinned."""
+reference executes here (BVH.cu does not build in this image), so like the live traversal it is parity-unpinned.
+
+Round 3 adds a second alternative rule over the same tree, RT_TRAVERSAL_WIDE4 (mode 2; SURVEY §8f rank 4 "wider nodes" — not in the reference, whose
+nodes are binary): a visit tests the up-to-four grandchild boxes, nearest first.  Same oracle twin / same bit-exact bar / same kernels as the queue."""
 import ctypes as C
 
 import numpy as np
@@ -78,17 +81,89 @@ def test_traversal_mode_is_validated_on_the_host():
     s = p.Scene.three_spheres()   # a HittableList: the queue belongs to BVH worlds
     s.set_traversal(1)
     assert s.getWorldPtr().traversal == 0
+    s.set_traversal(2)
+    assert s.getWorldPtr().traversal == 0
     with pytest.raises(p.capi.RtError):
-        s.set_traversal(2)
+        s.set_traversal(3)
     b = p.Scene.book1_final(1984).set_traversal(1)
     assert b.getWorldPtr().traversal == 1
+    assert b.set_traversal(2).getWorldPtr().traversal == 2
+
+
+def test_wide4_traversal_finds_the_same_hits():
+    """the 4-wide rule over the same tree: the same closest hits (rounding near-ties aside); it skips the intermediate children's boxes and tests
+    all four grandchildren instead, so it does MORE box tests per sample than the near-first binary walk, in about half the visits"""
+    s = O.Scene.book1_final(1984)
+    cam = O.camera_defocus((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, 1.5, 0.1, 10.0)
+    W, H, spp = 300, 200, 4
+    s.world.traversal = 0
+    ref, c0 = O.render(s.world, cam, W, H, spp, 50)
+    s.world.traversal = 2
+    img, c2 = O.render(s.world, cam, W, H, spp, 50)
+    assert np.nanmax(np.abs(img - ref)) < 1e-3
+    assert c2.max_stack <= 32
+    assert 0.8 * c0.box_tests < c2.box_tests < 2.0 * c0.box_tests
+    print(f"box tests per sample {c0.box_tests / c0.samples:.2f} -> {c2.box_tests / c2.samples:.2f}, "
+          f"leaf tests {c0.leaf_tests / c0.samples:.3f} -> {c2.leaf_tests / c2.samples:.3f}, stack {c0.max_stack} -> {c2.max_stack}")
+
+
+def _comb_world(cls, node_dt, prim_dt, mat_dt, levels=12):
+    """a tree that fills the 4-wide walk's stack: every level is N -> (A -> (N', leaf), B -> (leaf, leaf)), all boxes on the ray, N' nearest: a
+    visit of N pushes three leaves under N', so after k levels the stack holds 3k entries; 32 are exceeded at level 11.  The binary walk
+    needs 2 * levels + 2 <= 32 entries and is fine."""
+    n_nodes = 6 * levels + 1
+    n_leaves = 3 * levels + 1
+    nodes = np.zeros(n_nodes, dtype=node_dt)
+    prims = np.zeros(n_leaves, dtype=prim_dt)
+    mats = np.zeros(1, dtype=mat_dt)
+    mats["albedo"] = 0.5
+    leaf_count = [0]
+
+    def leaf(i):
+        k = leaf_count[0]
+        leaf_count[0] += 1
+        nodes[i]["min"], nodes[i]["max"] = (1.0, -1.0, -1.0), (100.0, 1.0, 1.0)
+        nodes[i]["left"], nodes[i]["right"] = -1, k
+        prims[k]["c0"], prims[k]["radius"], prims[k]["c1"], prims[k]["mat"] = (50.0 + k * 0.01, 0.0, 0.0), 0.5, (0, 0, 0), 0
+
+    for lv in range(levels):
+        n, a, b, l1, l2, l3 = (6 * lv + j for j in range(6))
+        for i in (n, a, b):
+            nodes[i]["min"], nodes[i]["max"] = (0.0, -1.0, -1.0), (100.0, 1.0, 1.0)
+        nodes[n]["left"], nodes[n]["right"] = a, b
+        nodes[a]["left"], nodes[a]["right"] = 6 * (lv + 1), l1
+        nodes[b]["left"], nodes[b]["right"] = l2, l3
+        leaf(l1), leaf(l2), leaf(l3)
+    leaf(6 * levels)
+    nodes[6 * levels]["min"] = (0.0, -1.0, -1.0)
+    w = cls()
+    w.kind, w.root, w.n_nodes, w.n_prims, w.n_materials, w.max_stack = 0, 0, n_nodes, n_leaves, 1, 2 * levels + 2
+    for k in range(3):
+        w.bounds_min[k], w.bounds_max[k] = float(nodes[0]["min"][k]), float(nodes[0]["max"][k])
+    w.nodes, w.prims, w.materials = nodes.ctypes.data, prims.ctypes.data, mats.ctypes.data
+    w.traversal = 2
+    return w, (nodes, prims, mats)
+
+
+def test_wide4_overflow_is_reported_by_the_oracle():
+    w, keep = _comb_world(O.World, O.NODE_DT, O.PRIM_DT, O.MAT_DT)
+    rays = np.float32([[-10, 0, 0, 1, 0, 0, 0]])
+    rc, *_ = _trace_oracle(w, rays)
+    assert rc == 4
+    w.traversal = 0
+    rc, hit, t, prim, _ = _trace_oracle(w, rays)
+    assert rc == 0 and hit[0] == 1 and prim[0] == 0
+    w9, keep9 = _comb_world(O.World, O.NODE_DT, O.PRIM_DT, O.MAT_DT, levels=9)    # 3 * 9 + 1 = 28 entries: fits
+    rc, hit, t, prim, _ = _trace_oracle(w9, rays)
+    assert rc == 0 and hit[0] == 1 and prim[0] == 0
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("which", ["book1_final", "book2_moving", "cornell_box", "book2_final"])
-def test_queue_traversal_on_the_gpu_matches_the_oracle_bit_for_bit(which):
+def test_queue_traversal_on_the_gpu_matches_the_oracle_bit_for_bit(which, mode):
     p = pkg()
-    s = config_scene(p, which).set_traversal(1)
+    s = config_scene(p, which).set_traversal(mode)
     w = s.getWorldPtr()
     rng = np.random.default_rng(8)
     n = 8192
@@ -113,13 +188,14 @@ def test_queue_traversal_on_the_gpu_matches_the_oracle_bit_for_bit(which):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2])
 @pytest.mark.parametrize("which,W,H,spp", [("book1_final", 120, 80, 8), ("book2_moving", 96, 64, 9), ("cornell_box", 72, 72, 12), ("book2_final", 64, 40, 6)])
-def test_queue_traversal_renders_on_the_streaming_kernel_bit_for_bit(which, W, H, spp):
+def test_queue_traversal_renders_on_the_streaming_kernel_bit_for_bit(which, W, H, spp, mode):
     """round 3: a RT_TRAVERSAL_QUEUE world renders on the streaming kernel (its RT_WORLD_BVH_QUEUE mode: every lane walks its trace with the
     distance-sorted queue when the trace begins, the samples are resolved in order): the framebuffer IS the oracle's; the baseline kernel
     (variant 1) still takes it, up to the summation order; the stack-walking variants refuse it"""
     p = pkg()
-    s = config_scene(p, which).set_traversal(1)
+    s = config_scene(p, which).set_traversal(mode)
     cam = config_cameras(p, which, W, H)
     w = s.getWorldPtr()
     r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, w)
@@ -141,11 +217,12 @@ def test_queue_traversal_renders_on_the_streaming_kernel_bit_for_bit(which, W, H
 
 
 @pytest.mark.gpu
-def test_queue_traversal_streaming_multi_pass_and_sharded(monkeypatch):
+@pytest.mark.parametrize("mode", [1, 2])
+def test_queue_traversal_streaming_multi_pass_and_sharded(monkeypatch, mode):
     import torch
     p = pkg()
     W, H, spp = 203, 117, 10
-    s = config_scene(p, "book1_final").set_traversal(1)
+    s = config_scene(p, "book1_final").set_traversal(mode)
     cam = config_cameras(p, "book1_final", W, H)
     w = s.getWorldPtr()
     ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, 50)
@@ -172,13 +249,15 @@ def test_queue_traversal_streaming_multi_pass_and_sharded(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_queue_overflow_is_reported_by_the_gpu_never_silent():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_queue_overflow_is_reported_by_the_gpu_never_silent(mode):
     p = pkg()
-    w, keep = _onion_world(p.capi.WorldFlat, p.capi.NODE_DT, p.capi.PRIM_DT, p.capi.MAT_DT)
+    make = _onion_world if mode == 1 else _comb_world
+    w, keep = make(p.capi.WorldFlat, p.capi.NODE_DT, p.capi.PRIM_DT, p.capi.MAT_DT)
     rays = np.float32([[-10, 0, 0, 1, 0, 0, 0]] * 64)
     with pytest.raises(p.capi.RtError) as e:
         p.api.probe_trace(w, rays)
-    assert e.value.code == 4 and "queue" in str(e.value)
+    assert e.value.code == 4 and ("queue" if mode == 1 else "4-wide") in str(e.value)
     # the same through the renderer (streaming kernel, queue mode): Render() reports the overflow
     cam = p.PinholeCamera((-10, 0, 0), (0, 0, 0), (0, 1, 0), 20.0, 1.0)
     r = p.Renderer.MakeRenderer(32, 32, 2, 8, cam, w)

@@ -72,8 +72,8 @@ def make_world(rng):
     # big worlds: the two O(n log n) builders, and (round 2) now and then a HittableList — the global-memory form of the list kernel
     builder = int(rng.integers(0, 4)) if not big else (3 if rng.random() < 0.08 else int(rng.integers(0, 2)))
     [s.BuildBVH_TopDown, s.BuildBVH_SAH, s.BuildBVH_BottomUp, s.MakeHittableList][builder]()
-    if builder != 3 and rng.random() < 0.05:
-        s.set_traversal(1)   # the distance-sorted queue (baseline kernel): an overflow of its 32 entries is a refusal, not a failure
+    if builder != 3 and rng.random() < 0.08:
+        s.set_traversal(1 + int(rng.integers(0, 2)))   # the distance-sorted queue or the 4-wide walk: an overflow of the 32 entries is a refusal, not a failure
     return s, kinds, builder, big
 
 
@@ -126,6 +126,8 @@ for seed in range(args.first, args.first + args.seeds):
         r.Render(); img = r.DownloadRenderbuffer(); r.close()
     ref, _ = O.render(as_oracle_world(w), as_oracle_camera(cam), W, H, spp, depth)
     stats["baseline" if info["variant"] == 1 else ("xchg" if info["variant"] == 5 else ("lds" if info["lds_resident"] else "global"))] += 1
+    if w.traversal:
+        stats[("queue", "wide4")[w.traversal - 1]] = stats.get(("queue", "wide4")[w.traversal - 1], 0) + 1
     if info["variant"] == 1:
         ok = np.array_equal(np.isnan(img), np.isnan(ref)) and float(np.nanmax(np.abs(img - ref))) <= 1e-5 * max(1.0, float(np.nanmax(ref)))
     else:
