@@ -140,14 +140,14 @@ def test_multi_renderer_memcpy_transport_multi_pass_and_explicit_devices(monkeyp
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,traversal", [("book2_final", 0), ("book1_final", 1), ("cornell_box", 1)])
+@pytest.mark.parametrize("which,traversal", [("book2_final", 0), ("book1_final", 1), ("cornell_box", 1), ("book2_moving", 2)])
 def test_multi_renderer_memcpy_transport_on_the_global_memory_and_queue_kernels(monkeypatch, which, traversal):
     """the same N > 1 branch over the other kernel families: the global-memory form (Book-2 final scene) and the queue mode"""
     p = pkg()
     W, H, spp, depth = 160, 96, 6, 50
     scene, cam = config_scene(p, which), config_cameras(p, which, W, H)
     if traversal:
-        scene.set_traversal(1)
+        scene.set_traversal(traversal)
     w = scene.getWorldPtr()
     r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
     r.Render()

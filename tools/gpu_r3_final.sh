@@ -12,5 +12,7 @@ timeout -k 10 500 python bench.py --workload book2_final --steps 1 --warmup 0 --
 cut -c1-250 gpurun_out/r03_config5_full.json
 timeout -k 10 200 python tools/config5_shard.py 10000 8 2>/dev/null > gpurun_out/r03_config5_shard.json
 cat gpurun_out/r03_config5_shard.json
+timeout -k 10 200 python tools/queue_perf.py 64 > gpurun_out/r03_traversal_modes_perf.txt 2>/dev/null
+cat gpurun_out/r03_traversal_modes_perf.txt
 timeout -k 10 600 python tools/fuzz_campaign.py --seeds 20000 --first 30000 --variants > gpurun_out/fuzz_r03v.txt 2>&1 || { tail -5 gpurun_out/fuzz_r03v.txt; exit 1; }
 tail -1 gpurun_out/fuzz_r03v.txt

@@ -10,7 +10,7 @@ W, H, spp = 1200, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 cam = p.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
 for label, traversal, variant in (("stack walk, streaming kernel (variant 3)", 0, 0), ("queue, streaming kernel (queue mode of variant 2)", 1, 0), ("queue, baseline kernel (variant 1)", 1, 1),
                                  ("4-wide walk, streaming kernel (lane-walk mode)", 2, 0), ("4-wide walk, baseline kernel (variant 1)", 2, 1), ("stack walk, baseline kernel (variant 1)", 0, 1),
-                                 ("stack walk, streaming kernel variant 2 (global nodes)", 0, 2)):
+                                 ("stack walk, streaming kernel variant 2 (IEEE divisions)", 0, 2)):
     s = p.Scene.book1_final(1984).set_traversal(traversal)
     r = p.Renderer.MakeRenderer(W, H, spp, 50, cam, s.getWorldPtr(), variant=variant)
     best = 1e30
