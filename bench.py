@@ -419,7 +419,8 @@ def main():
                 "library_matches_tree_sources": bool(lib_hash == pkg.capi.source_hash()),
                 "counters_stale": (None if pmc_src is None else bool(pmc_stamp != lib_hash)),
                 "counts_per_sample": {k: round(v, 3) for k, v in counts.items()},
-                "hbm": {"note": "secondary: the scene (60 KB) is LDS-resident, the algorithmic bytes are served from the LDS and HBM is not the roof",
+                "hbm": {"note": ("secondary: the scene is LDS-resident, the algorithmic bytes are served from the LDS and HBM is not the roof" if kinfo["lds_resident"] else
+                                 "secondary: the scene's records are read through the vector L1 / L2 (global-memory form of the kernel, top of the tree in the LDS); the algorithmic bytes are cache-served and HBM is not the roof"),
                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
                         "algorithmic_GBps": round(bytes_per_sample * launch_samples / (stream_ms * 1e-3) / 1e9, 1),
                         "measured_bytes_per_launch": traffic,
