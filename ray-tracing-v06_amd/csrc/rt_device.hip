@@ -63,6 +63,17 @@ struct DevBuf {
 static void write_wide_node(uint4* blob, bool big, uint32_t index, const float lmin[3], const float lmax[3], const float rmin[3],
                             const float rmax[3], uint32_t lref, uint32_t rref) {
     auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+#ifdef RT_BIG_TRIPLES
+    if (big) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * RT_NODE_DWORDS_BIG;
+        for (int k = 0; k < 3; k++) {
+            d[3 * k + 0] = bits(lmin[k]); d[3 * k + 1] = bits(lmax[k]); d[3 * k + 2] = bits(lmin[k]);
+            d[9 + 3 * k + 0] = bits(rmin[k]); d[9 + 3 * k + 1] = bits(rmax[k]); d[9 + 3 * k + 2] = bits(rmin[k]);
+        }
+        d[18] = lref; d[19] = rref;
+        return;
+    }
+#endif
     if (big) {  // one 64-byte line: [lmin.xyz lmax.x | lmax.yz rmin.xy | rmin.z rmax.xyz | left right - -]
         uint32_t* d = reinterpret_cast<uint32_t*>(blob) + (size_t)index * RT_NODE_DWORDS_BIG;
         const float v[12] = {lmin[0], lmin[1], lmin[2], lmax[0], lmax[1], lmax[2], rmin[0], rmin[1], rmin[2], rmax[0], rmax[1], rmax[2]};
@@ -90,7 +101,8 @@ struct DeviceScene {
     bool big = false;            // packed for the global-memory kernel (the image does not fit the LDS): 64-byte nodes, breadth-first
     bool wide = false;           // ... with 32-bit references (2^14 inner nodes / 2^15 leaf codes or more); otherwise 16-bit like the LDS image
     bool any_moving = false;     // a MovingSphere is in the world: the leaf phase reads the second centres
-    bool queue = false;          // RT_TRAVERSAL_QUEUE: BVH.cu:17-49's distance-sorted walk (the streaming kernel's RT_WORLD_BVH_QUEUE mode, records in global memory)
+    bool queue = false;          // RT_TRAVERSAL_QUEUE (BVH.cu:17-49's distance-sorted walk) or RT_TRAVERSAL_WIDE4: every lane walks its whole trace on its own
+                                 // (the streaming kernel's RT_WORLD_BVH_QUEUE mode, records in global memory)
 
     // Re-pack an RT_WORLD_BVH world into the LDS image of render_kernel_stream: 76-B wide nodes (both
     // child boxes + references), 16-B sphere records, 16-B (centre1, material) records.
@@ -491,6 +503,9 @@ struct rt_renderer {
                 top_bytes = std::min(top_bytes & ~63u, scene.packed.n_inner * (RT_NODE_DWORDS_BIG * 4u));
                 if (const char* env = std::getenv("RT06_TOP_NODES")) top_bytes = std::min(top_bytes, (uint32_t)std::atoi(env) * (RT_NODE_DWORDS_BIG * 4u));
                 if (scene.queue) top_bytes = 0;   // the queue walk reads the flat world's own nodes
+#ifdef RT_BIG_TRIPLES
+                top_bytes = 0;
+#endif
                 n_top = top_bytes / (RT_NODE_DWORDS_BIG * 4u);
                 stream_lds_bytes = top_bytes + stacks;
             } else {
@@ -503,7 +518,7 @@ struct rt_renderer {
         }
         const bool can_xchg = can_stream && !scene.big && !scene.extended && scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && !scene.queue;
         if (scene.queue && want >= 3)
-            return rt_fail(RT_ERR_INVALID, "kernel variants 3 to 5 walk the tree with the stack of BVH.cu:54-106: a world with the distance-sorted queue (RT_TRAVERSAL_QUEUE) renders on variant 2 (or 0) and on the baseline kernel (1)");
+            return rt_fail(RT_ERR_INVALID, "kernel variants 3 to 5 walk the tree with the stack of BVH.cu:54-106: a world with another traversal rule (RT_TRAVERSAL_QUEUE, RT_TRAVERSAL_WIDE4) renders on variant 2 (or 0) and on the baseline kernel (1)");
         if (want == 0) want = can_stream ? ((scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && !scene.queue) ? 3u : 2u) : 1u;
         if (want == 3 && cfg.variant == 0 && can_xchg) {
             const char* env = std::getenv("RT06_DEFAULT_XCHG");
@@ -606,7 +621,7 @@ struct rt_renderer {
     const void* stream_kernel_ptr() const {
         if (variant == 5) return reinterpret_cast<const void*>(&render_kernel_xchg<RT_XCHG_BLOCK>);
         const bool fast = variant == 3;
-        if (scene.queue) {   // the distance-sorted queue: one instantiation per feature level, records in global memory, 32-bit references
+        if (scene.queue) {   // the distance-sorted queue / the 4-wide walk: one instantiation per feature level, records in global memory, 32-bit references
             if (scene.textured) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH_QUEUE, 2, true, true>);
             if (scene.extended) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH_QUEUE, 1, true, true>);
             return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH_QUEUE, 0, true, true>);
@@ -1135,7 +1150,7 @@ extern "C" int rt_multi_renderer_render(rt_multi_renderer* m) {
         HIP_TRY(hipSetDevice(m->devices[i]));
         HIP_TRY(hipStreamSynchronize(m->parts[i]->stream));
     }
-    for (uint32_t i = 0; i < n; i++) {   // RT_TRAVERSAL_QUEUE worlds (baseline kernel): an overflowed queue is an error here too
+    for (uint32_t i = 0; i < n; i++) {   // RT_TRAVERSAL_QUEUE / _WIDE4 worlds: an overflow of the 32 entries is an error here too
         HIP_TRY(hipSetDevice(m->devices[i]));
         int rc = check_xchg_error(m->parts[i]->xchg_error);
         if (rc == RT_OK) rc = check_traversal_overflow(m->parts[i]->scene);

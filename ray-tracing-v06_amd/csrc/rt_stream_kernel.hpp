@@ -73,7 +73,11 @@
 // rmin.z rmax.xyz | left, right, -, -], and near / far planes are picked with selects instead of by address.
 #define RT_REF_LEAF_BIG 0x80000000u
 #define RT_REF_IRR_BIG 0x40000000u
+#ifdef RT_BIG_TRIPLES   // experiment: the LDS image's (min, max, min) triples in global memory too — (near, far) pairs by address, 80-byte nodes
+#define RT_NODE_DWORDS_BIG 20u
+#else
 #define RT_NODE_DWORDS_BIG 16u
+#endif
 // number of 16-B units the node region of `n` wide nodes occupies in the blob
 #define RT_NODES_VEC4(n, big) (((n) * ((big) ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) + 3u) / 4u)
 
@@ -209,6 +213,20 @@ template <bool BIG>
 __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const uint4* top, uint32_t n_top, uint32_t idx,
                                                         uint32_t kx, uint32_t ky, uint32_t kz) {
     WideNodeData n;
+#ifdef RT_BIG_TRIPLES
+    if (BIG) {
+        const uint32_t nb = idx * (RT_NODE_DWORDS_BIG * 4u);
+        const float* px = reinterpret_cast<const float*>(nodes + (nb + kx));
+        const float* py = reinterpret_cast<const float*>(nodes + (nb + ky));
+        const float* pz = reinterpret_cast<const float*>(nodes + (nb + kz));
+        n.lnx = px[0]; n.lfx = px[1]; n.rnx = px[9]; n.rfx = px[10];
+        n.lny = py[3]; n.lfy = py[4]; n.rny = py[12]; n.rfy = py[13];
+        n.lnz = pz[6]; n.lfz = pz[7]; n.rnz = pz[15]; n.rfz = pz[16];
+        const uint2 refs = *reinterpret_cast<const uint2*>(nodes + nb + 72u);
+        n.left = refs.x; n.right = refs.y;
+        return n;
+    }
+#endif
     if (BIG) {
         float4 a, b, c;
         uint4 r;
