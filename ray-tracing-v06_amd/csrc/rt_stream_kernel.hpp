@@ -352,7 +352,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     // ---- wave-uniform work pool: sample indices [pool_next, pool_end) ----------------------------------
     // The FIRST chunk of a wave is its own (chunk number = the wave's number in the grid; the host starts the shared counter behind
     // them): 6144 waves asking one counter at once take ~70 us (one word serves ~88 returning atomics per us), which a 1/8 shard feels.
-    uint32_t pool_next = min((blockIdx.x * (BLOCK / 64u) + wave) * p.chunk, p.total);
+    // (readfirstlane: the wave's number is uniform, which the compiler cannot see in threadIdx.x >> 6 — the pool stays in scalar registers)
+    uint32_t pool_next = min((blockIdx.x * (BLOCK / 64u) + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave)) * p.chunk, p.total);
     uint32_t pool_end = min(pool_next + p.chunk, p.total);
     bool pool_dry = false;
 
@@ -431,6 +432,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
             bool at_inner = cur < K_IRR;
             if (__ballot(at_inner) != 0ull) {
                 uint32_t n_inner_lanes;
+                // inner_keep >= 1 (host); once the queue is dry the wave only drains its last paths: no reason to leave early.  The threshold is
+                // wave-uniform; readfirstlane tells the compiler so (a scalar compare and branch instead of a vector compare and an exec-mask loop exit)
+                const uint32_t keep_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pool_dry ? 1u : p.inner_keep));
                 do {
                     if (at_inner) {
 #ifdef RT_BRANCHLESS_STACK
@@ -471,8 +475,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
 #ifdef RT_PHASE_TIMERS
                     pc_[6]++;
 #endif
-                } while (n_inner_lanes >= (pool_dry ? 1u : p.inner_keep));   // inner_keep >= 1 (host); once the queue is dry the wave
-                                                                              // only drains its last paths: no reason to leave early
+                } while (n_inner_lanes >= keep_now);
             }
             RT_PT(0);
             if (irr_pending) {   // wave-uniform, rare: rays with a zero / tiny / huge direction or origin component
@@ -774,6 +777,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 // all three 16-byte parts of the record go out together: ONE global round trip (a padding pixel's two extra loads are wasted, rarely)
                 const uint4 rs = RT_LOAD_ONCE(p.prim_rng + n);
                 const float4 po = RT_LOAD_ONCE(p.prim_o + n), pd = RT_LOAD_ONCE(p.prim_d + n);
+                asm volatile("" : : "v"(po.x), "v"(pd.x));   // keeps the compiler from sinking the two loads below the test (a second, dependent round trip)
                 if ((rs.x | rs.y | rs.z | rs.w) != 0u) {
                     out_idx = n;
                     ray.o = mk3(po.x, po.y, po.z); ray.d = mk3(pd.x, pd.y, pd.z); ray.time = po.w;
