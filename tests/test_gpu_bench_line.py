@@ -48,3 +48,30 @@ def test_multi_pass_workload_line(monkeypatch):
     assert sum(r["other_kernels_ms"].values()) + r["kernel_ms"] <= 1.05 * d["kernel_ms_per_step_rank0"]
     assert r["counters_source"].endswith("cornell_box_pmc_summary.csv") and r["counters_scaled_from_spp"] == 1000 and 0.3 < r["frac"] <= 1.0
     assert d["parity"]["bit_identical"] is True and d["parity_timed_frame"]["bit_identical"] is True
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("ranks,pipeline", [(2, "1"), (3, "1"), (2, "2")])
+def test_n_gt_1_line_rehearsed_on_one_gpu(ranks, pipeline):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one process per rank), rehearsed on this one-GPU box: every rank
+    renders its tile shard on cuda:0, the frame-end gather goes over gloo instead of RCCL (RCCL refuses two ranks on one device), rank 0 assembles
+    and — after the timed region — verifies the assembled frame against the frame it renders alone, bit for bit.  Everything of the N > 1 path
+    but the transport itself: shard buffers, stream / event ordering (also with two frames in flight), max-over-ranks timing, the ONE JSON line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--backend", "gloo", "--same-device",
+           "--width", "243", "--height", "161", "--spp", "12", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--pipeline", pipeline]
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == ranks and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
+    assert abs(d["value"] - 243 * 161 * 12 / d["ms_per_step"] / 1e3) < 1e-2 * d["value"]
+    assert d["assembly_verified"] is True
+    assert d["config"]["frames_in_flight"] == int(pipeline)
