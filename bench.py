@@ -413,7 +413,9 @@ def main():
                     "resolve_kernel": {"algorithmic_bytes_per_sample": 16, "GBps": round(16.0 * launch_samples / (resolve_ms * 1e-3) / 1e9, 1),
                                        "frac_of_peak": round(16.0 * launch_samples / (resolve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
                 "peak_definition": f"{n_simd} SIMDs x {clock_ghz:.3f} GHz / 2 cycles per wave64 fp32 add/mul/fma (tools/bench_valu_issue.hip); compares, selects, min/max "
-                                   "issue in 4 cycles and scalar instructions are not hidden, so frac = 1 is not reachable by this instruction mix",
+                                   "issue in 4 cycles and scalar instructions are not hidden, so frac = 1 is not reachable by this instruction mix; measured: a pure "
+                                   "v_fma_f32 stream (128 per loop iteration, tools/bench_valu_peak.hip, profiles/r03_valu_peak_microbench.txt) sustains 898 G/s "
+                                   "= 0.73 of this peak at the kernel's occupancy (6 waves per SIMD; 950 G/s at 8), because the shader clock sags to ~1.95 GHz under it",
                 "samples_per_launch": launch_samples,
                 "counters_source": pmc_src, "counters_source_csrc_sha256": pmc_stamp, "library_csrc_sha256": lib_hash,
                 "library_matches_tree_sources": bool(lib_hash == pkg.capi.source_hash()),
