@@ -309,8 +309,9 @@ int rt_renderer_last_kernel_ms(rt_renderer* r, float* out_ms);
 int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms[3]);
 /* How a render is cut into passes: out[0] = passes per render, out[1] = samples per pixel per pass, out[2] = HBM bytes per
  * sample index of a pass (12 B radiance + 48 B primary-ray record), out[3] = bytes of the per-pass buffers this renderer
- * holds (sample buffer + primary rays + running sums).  A pass is sized by a budget over ALL of those buffers: 40 GiB by
- * default, RT06_PASS_BUDGET_BYTES to change it, RT06_PASS_SPP to force the samples per pixel per pass (tests).           */
+ * holds (sample buffer + primary rays + running sums).  A pass is sized by a budget over ALL of those buffers: 120 GiB by
+ * default but at most 45 % of the HBM that is free when the renderer is created (RT06_PASS_BUDGET_BYTES to change it, RT06_PASS_SPP to
+ * force the samples per pixel per pass: tests); if the device cannot provide the buffers the passes are halved until it can.           */
 int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]);
 /* Which kernel the renderer resolved to: out[0] = variant actually used (1..5), out[1] = 1 when the scene image is
  * LDS-resident (0: baseline kernel, or a world too large for the LDS, served from global memory / L2 with 32-bit

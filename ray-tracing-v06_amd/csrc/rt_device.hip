@@ -47,9 +47,14 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) {
-        if (p) { (void)hipFree(p); p = nullptr; }   // re-allocation (a scene packed twice) must not leak the first buffer
-        bytes = n;
-        return hipMalloc(&p, n ? n : 1);
+        release();   // re-allocation (a scene packed twice) must not leak the first buffer
+        const hipError_t e = hipMalloc(&p, n ? n : 1);
+        if (e == hipSuccess) bytes = n; else p = nullptr;
+        return e;
+    }
+    void release() {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = 0;
     }
     hipError_t upload(const void* src, size_t n) {
         hipError_t e = alloc(n);
@@ -587,8 +592,14 @@ struct rt_renderer {
         }
         if (variant >= 2) {
             // HBM of one pass: every sample index owns SAMPLE_BYTES of radiance + PRIMARY_BYTES of primary-ray record.  The default
-            // budget (40 GiB of the 288) gives the 1200x800x500 headline one pass (28.8 GB) and a 3840x2160 frame 86 spp per pass.
-            uint64_t budget = 40ull << 30;
+            // budget — 120 GiB of the 288, but never more than 45 % of what is free on the device right now, so that two renderers of a
+            // big frame can live side by side — gives the 1200x800x500 headline one pass (28.8 GB) and a 3840x2160 frame 258 spp per
+            // pass (40 GiB, round 2's default, gave 86: 117 passes instead of 39 for 10 000 spp cost 1.1 % in per-pass tails).
+            uint64_t budget = 120ull << 30;
+            {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)free_b / 100u * 45u);
+            }
             const uint64_t per_sample = SAMPLE_BYTES + PRIMARY_BYTES;
             if (const char* env = std::getenv("RT06_PASS_BUDGET_BYTES")) {  // bytes of ALL per-sample buffers of a pass
                 unsigned long long v = std::strtoull(env, nullptr, 10);
@@ -603,9 +614,18 @@ struct rt_renderer {
             max_spp = std::min<uint64_t>(max_spp, (0xF0000000ull - 1) / n_local_pixels);   // sample indices of a pass are 32 bits wide
             if (max_spp == 0) return rt_fail(RT_ERR_INVALID, "image too large for one pass");
             pass_spp = (uint32_t)std::min<uint64_t>(cfg.samples_per_pixel, max_spp);
+            for (;;) {   // a device that cannot give the pass its buffers gets smaller passes, not an error: halve until they fit
+                hipError_t e = samples.alloc((size_t)(n_local_pixels * pass_spp * SAMPLE_BYTES));
+                if (e == hipSuccess) e = primary[0].alloc((size_t)(n_local_pixels * pass_spp * PRIMARY_BYTES));
+                if (e == hipSuccess) break;
+                (void)hipGetLastError();   // (clears the sticky out-of-memory status)
+                samples.release(); primary[0].release();
+                if (e != hipErrorOutOfMemory || pass_spp == 1u)
+                    return rt_fail(RT_ERR_HIP, "per-pass buffers (%llu bytes per sample index x %llu sample indices): %s", (unsigned long long)per_sample,
+                                   (unsigned long long)(n_local_pixels * pass_spp), hipGetErrorString(e));
+                pass_spp = (pass_spp + 1u) / 2u;
+            }
             n_passes = (cfg.samples_per_pixel + pass_spp - 1) / pass_spp;
-            HIP_TRY(samples.alloc((size_t)(n_local_pixels * pass_spp * SAMPLE_BYTES)));
-            HIP_TRY(primary[0].alloc((size_t)(n_local_pixels * pass_spp * PRIMARY_BYTES)));
             if (n_passes > 1) HIP_TRY(running.alloc((size_t)(n_local_pixels * 16ull)));
             HIP_TRY(hipFuncSetAttribute(stream_kernel_ptr(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds_bytes));
             if (std::getenv("RT06_DEBUG")) {

@@ -67,19 +67,19 @@ def test_config5_geometry_3840x2160_sparse_parity_and_multi_pass(monkeypatch):
 
 
 def test_config5_at_its_own_resolution_with_natural_passes():
-    """configs[4] at 3840 x 2160, depth 50, with the REAL pass budget (40 GiB of per-sample buffers = 86 spp per pass at this size):
-    264 spp = 4 natural passes (86 + 86 + 86 + 6), i.e. the regime of the 10 000-spp run (117 passes) — running sums carried
-    from pass to pass, the work counter reset per pass, the per-pass buffers at their full size.  32 random pixels + the four
+    """configs[4] at 3840 x 2160, depth 50, with the REAL pass budget (120 GiB of per-sample buffers, or 45 % of the free HBM = up to 258 spp per
+    pass at this size): 800 spp = 4 natural passes (258 + 258 + 258 + 26), i.e. the regime of the 10 000-spp run (39 passes) — running sums
+    carried from pass to pass, the work counter reset per pass, the per-pass buffers at their full size (129 GB).  32 random pixels + the four
     corners against the CPU oracle, bit for bit."""
     p = pkg()
-    W, H, spp, depth = 3840, 2160, 264, 50
+    W, H, spp, depth = 3840, 2160, 800, 50
     scene, cam = config_scene(p, "book2_final"), config_cameras(p, "book2_final", W, H)
     w = scene.getWorldPtr()
     r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, w)
     pi = r.pass_info()
     assert pi["n_passes"] >= 3 and pi["pass_spp"] * pi["n_passes"] >= spp, pi
-    assert pi["buffer_bytes"] <= (40 << 30) + W * H * 16, pi            # the budget covers EVERY per-sample buffer of the pass
-    assert pi["pass_spp"] * W * H * pi["bytes_per_sample"] <= 40 << 30, pi
+    assert pi["buffer_bytes"] <= (120 << 30) + W * H * 16, pi            # the budget covers EVERY per-sample buffer of the pass
+    assert pi["pass_spp"] * W * H * pi["bytes_per_sample"] <= 120 << 30, pi
     r.Render()
     img = r.DownloadRenderbuffer()
     times = r.kernel_times()
@@ -163,3 +163,20 @@ def test_config4_cornell_600x600_sharded_over_4_ranks_is_the_same_frame():
     got = _sharded(p, W, H, spp, depth, cam, w, 4)
     assert got.tobytes() == ref.tobytes()
     _sparse_check(ref, w, cam, W, H, spp, depth, 48, 44)
+
+
+def test_passes_shrink_when_the_device_cannot_hold_them(monkeypatch):
+    """a budget the device does not have (400 GiB of per-sample buffers on a 288-GB GPU) is not an error: the passes are halved until their
+    buffers fit (creation used to fail with hipMalloc's error instead of falling back to more passes)"""
+    import torch
+    p = pkg()
+    W, H, spp, depth = 3840, 2160, 5000, 50
+    scene, cam = config_scene(p, "book2_final"), config_cameras(p, "book2_final", W, H)
+    monkeypatch.setenv("RT06_PASS_BUDGET_BYTES", str(400 << 30))
+    asked = (400 << 30) // (W * H * 60)
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, scene.getWorldPtr())
+    pi = r.pass_info()
+    r.close()
+    total = torch.cuda.get_device_properties(0).total_memory
+    assert asked * W * H * 60 > total                      # what was asked for cannot exist on this device
+    assert pi["pass_spp"] < asked and pi["buffer_bytes"] < total and pi["pass_spp"] * pi["n_passes"] >= spp, pi
