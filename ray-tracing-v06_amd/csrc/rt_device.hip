@@ -152,7 +152,8 @@ struct DeviceScene {
         }
         if (n_inner >= ref_leaf) return RT_OK;
         const uint32_t nodes_vec4 = RT_NODES_VEC4(n_inner, big);
-        size_t n_vec4 = (size_t)nodes_vec4 + (size_t)w->n_prims * 2 + (size_t)w->n_materials + (size_t)w->n_quads * 5;
+        const uint32_t quads_at = (nodes_vec4 + w->n_prims * 2 + w->n_materials + 3u) & ~3u;   // 64-byte records on 64-byte boundaries: one cache line each
+        size_t n_vec4 = (size_t)quads_at + (size_t)w->n_quads * 5;
         std::vector<uint4> host(n_vec4, make_uint4(0, 0, 0, 0));
         if (w->kind == RT_WORLD_BVH) {
             auto ref_of = [&](int32_t node) -> uint32_t {
@@ -203,14 +204,16 @@ struct DeviceScene {
             const rt_material& m = w->materials[i];
             m16[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.param);
         }
-        float4* qd = m16 + w->n_materials;
+        float4* qd = reinterpret_cast<float4*>(host.data()) + quads_at;
         for (uint32_t i = 0; i < w->n_quads; i++) {
             const rt_quad& q = w->quads[i];
-            qd[5 * i + 0] = make_float4(q.Q[0], q.Q[1], q.Q[2], q.D);
-            qd[5 * i + 1] = make_float4(q.u[0], q.u[1], q.u[2], __uint_as_float_host(mat_bits(q.mat, 0u)));
-            qd[5 * i + 2] = make_float4(q.v[0], q.v[1], q.v[2], 0.0f);
-            qd[5 * i + 3] = make_float4(q.normal[0], q.normal[1], q.normal[2], 0.0f);
-            qd[5 * i + 4] = make_float4(q.w[0], q.w[1], q.w[2], 0.0f);
+            // 64 bytes, what quad::hit reads, in four 16-byte parts; what the shade phase reads of a quad — (normal, material) — is one
+            // 16-byte record of its own behind the quads
+            qd[4 * i + 0] = make_float4(q.Q[0], q.Q[1], q.Q[2], q.D);
+            qd[4 * i + 1] = make_float4(q.u[0], q.u[1], q.u[2], q.v[0]);
+            qd[4 * i + 2] = make_float4(q.v[1], q.v[2], q.normal[0], q.normal[1]);
+            qd[4 * i + 3] = make_float4(q.normal[2], q.w[0], q.w[1], q.w[2]);
+            qd[4 * (size_t)w->n_quads + i] = make_float4(q.normal[0], q.normal[1], q.normal[2], __uint_as_float_host(mat_bits(q.mat, 0u)));
         }
         HIP_TRY(blob.upload(host.data(), n_vec4 * sizeof(uint4)));
         packed.blob = blob.as<uint4>();
@@ -218,7 +221,7 @@ struct DeviceScene {
         packed.off_spheres = nodes_vec4;
         packed.off_extra = nodes_vec4 + w->n_prims;
         packed.off_mats = nodes_vec4 + w->n_prims * 2;
-        packed.off_quads = nodes_vec4 + w->n_prims * 2 + w->n_materials;
+        packed.off_quads = quads_at;
         packed.sphere_codes = sphere_codes;
         packed.background = w->background;
         for (int k = 0; k < 3; k++) packed.background_color[k] = w->background_color[k];

@@ -82,7 +82,7 @@
 #define RT_NODES_VEC4(n, big) (((n) * ((big) ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) + 3u) / 4u)
 
 // LDS image, in 16-B units:  [wide nodes (RT_NODE_DWORDS dwords each, region rounded up) | spheres (c0, r) | extra (c1, matbits) | mats16 (albedo, param) |
-//                              quads (5 each: Q,D | u,matbits | v | normal | w)],   matbits = material index | moving << 28 | type << 29
+//                              (padding to a 64-byte boundary) quads (4 each: Q,D | u,v.x | v.yz,n.xy | n.z,w) | quad shade records (normal, matbits)],   matbits = material index | moving << 28 | type << 29
 struct PackedSceneRef {
     const uint4* blob;
     uint32_t blob_vec4;      // number of 16-B units to stage into LDS
@@ -576,12 +576,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                     const uint32_t first_quad = (WORLD == RT_WORLD_LIST) ? p.scene.n_prims : p.scene.sphere_codes;
                     if (EXT && code >= first_quad) {
                         // quad::hit ("The Next Week"), reference conventions: see quad_closest_intersection()
-                        const float4* qd = quads + (code - first_quad) * 5u;
-                        float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a3 = qd[3], a4 = qd[4];
+                        const float4* qd = quads + (code - first_quad) * 4u;
+                        float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a3 = qd[3];
                         HitRec tmp;
                         tmp.distance = rec_t; tmp.normal = mk3(0.0f); tmp.prim = -1; tmp.mat = 0;
-                        if (quad_closest_intersection(mk3(a0.x, a0.y, a0.z), a0.w, mk3(a1.x, a1.y, a1.z), mk3(a2.x, a2.y, a2.z),
-                                                      mk3(a3.x, a3.y, a3.z), mk3(a4.x, a4.y, a4.z), 0u, 0, ray, tmp)) {
+                        if (quad_closest_intersection(mk3(a0.x, a0.y, a0.z), a0.w, mk3(a1.x, a1.y, a1.z), mk3(a1.w, a2.x, a2.y),
+                                                      mk3(a2.z, a2.w, a3.x), mk3(a3.y, a3.z, a3.w), 0u, 0, ray, tmp)) {
                             rec_t = tmp.distance;
                             rec_code = (int32_t)(code - first_quad + p.scene.sphere_codes);   // the shade phase's code space
                         }
@@ -660,11 +660,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 f3 normal;
                 uint32_t mat_bits;
                 if (EXT && (uint32_t)rec_code >= p.scene.sphere_codes) {
-                    const float4* qd = quads + ((uint32_t)rec_code - p.scene.sphere_codes) * 5u;
-                    float4 a1 = qd[1], a3 = qd[3];
-                    normal = mk3(a3.x, a3.y, a3.z);
+                    const float4 qs = quads[p.scene.n_quads * 4u + ((uint32_t)rec_code - p.scene.sphere_codes)];   // the quad's shade record
+                    normal = mk3(qs.x, qs.y, qs.z);
                     if (dot(ray.d, normal) > 0) normal = -normal;  // the book's set_face_normal: a quad is two-sided
-                    mat_bits = __float_as_uint(a1.w);
+                    mat_bits = __float_as_uint(qs.w);
                 } else {
                     uint32_t prim = (uint32_t)rec_code >> 1;
                     float4 sph = spheres[prim];
@@ -730,10 +729,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_NOISE) albedo = noise_value(p.scene.perlin, albedo, mparam, hit_p);
                         if (EXT >= 2 && mtype == RT_MAT_LAMBERTIAN_IMAGE) {
                             if ((uint32_t)rec_code >= p.scene.sphere_codes) {   // on a quad: (u, v) = the planar coordinates of the hit
-                                const float4* qd = quads + ((uint32_t)rec_code - p.scene.sphere_codes) * 5u;
-                                const float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a4 = qd[4];
+                                const float4* qd = quads + ((uint32_t)rec_code - p.scene.sphere_codes) * 4u;
+                                const float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a3 = qd[3];
                                 albedo = image_value_quad(p.scene.image, p.scene.image_w, p.scene.image_h, mk3(a0.x, a0.y, a0.z), mk3(a1.x, a1.y, a1.z),
-                                                          mk3(a2.x, a2.y, a2.z), mk3(a4.x, a4.y, a4.z), hit_p);
+                                                          mk3(a1.w, a2.x, a2.y), mk3(a3.y, a3.z, a3.w), hit_p);
                             } else {
                                 albedo = image_value(p.scene.image, p.scene.image_w, p.scene.image_h, normal);
                             }
