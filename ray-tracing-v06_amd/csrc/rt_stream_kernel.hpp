@@ -578,6 +578,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         // quad::hit ("The Next Week"), reference conventions: see quad_closest_intersection()
                         const float4* qd = quads + (code - first_quad) * 4u;
                         float4 a0 = qd[0], a1 = qd[1], a2 = qd[2], a3 = qd[3];
+                        // all four parts in ONE round trip: left alone, the compiler sinks the reads of (Q, D) below the tests that use the normal — three
+                        // dependent round trips per quad test, which the global-memory form feels
+                        asm volatile("" : : "v"(a0.x), "v"(a0.w));
                         HitRec tmp;
                         tmp.distance = rec_t; tmp.normal = mk3(0.0f); tmp.prim = -1; tmp.mat = 0;
                         if (quad_closest_intersection(mk3(a0.x, a0.y, a0.z), a0.w, mk3(a1.x, a1.y, a1.z), mk3(a1.w, a2.x, a2.y),
