@@ -467,6 +467,7 @@ struct rt_renderer {
     uint32_t stream_block = RT_STREAM_BLOCK;
     uint32_t stream_blocks_per_cu = 0;
     uint32_t variant = 0;        // resolved kernel variant (see rt_render_config::variant)
+    uint32_t tol = 0;            // 1 / 2: variant 3 with the tolerance-mode box test (requested as variant 6 / 7)
     uint32_t tune[3] = {RT_INNER_KEEP, RT_SHADE_MIN, RT_LEAF_MIN};  // scheduling thresholds of the streaming kernel
     // render_kernel_xchg (variant 5): roles, ring capacities, population and thresholds (RT06_XCHG=tracers,extra,swap,shade,patience,prio)
     struct { uint32_t n_tracers = 9, tq_cap = 0, sq_cap = 0, pop_extra = 192, swap_min = 16, shade_min = 48, patience = 6, prio = 1, scene_vec4 = 0, extra_in_lds = 0, keep = 44, shards = 1; } xc;
@@ -494,7 +495,9 @@ struct rt_renderer {
         n_cus = (uint32_t)prop.multiProcessorCount;
         const uint32_t lds_per_cu = 160u * 1024u;  // MI355X_MICROARCH.md: 160 KiB LDS per CU
         uint32_t want = cfg.variant;
-        if (want > 5) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
+        if (want > 7) return rt_fail(RT_ERR_INVALID, "unknown kernel variant %u", want);
+        const uint32_t tol_form = want >= 6 ? want - 5u : 0u;   // variants 6 / 7: variant 3 with the tolerance-mode box test (NOT bit-exact; opt-in measurement)
+        if (tol_form) want = 3;
         bool can_stream = scene.has_packed;
         if (can_stream) {
             stream_block = RT_STREAM_BLOCK;
@@ -545,6 +548,11 @@ struct rt_renderer {
         if (want >= 3 && !scene.regular_boxes)
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
+        if (tol_form) {
+            if (scene.big || scene.extended || stream_block != RT_STREAM_BLOCK)
+                return rt_fail(RT_ERR_INVALID, "kernel variants 6 and 7 (tolerance-mode box test) are instantiated for LDS-resident worlds of the reference's feature set only");
+            tol = tol_form;
+        }
         if (variant == 5) {
             // LDS of a workgroup (two per CU): nodes | spheres | (second centres when a sphere moves) | tracer stacks | rings
             stream_block = RT_XCHG_BLOCK;
@@ -672,6 +680,8 @@ struct rt_renderer {
         }
         if (scene.dw.kind == RT_WORLD_LIST) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST>);
         if (scene.dw.kind == RT_WORLD_NODE_TREE) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_NODE_TREE>);
+        if (tol == 1) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 0, false, false, 1>);
+        if (tol == 2) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 0, false, false, 2>);
         if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768>);
         if (variant == 4) return reinterpret_cast<const void*>(&render_kernel_stream<false, true, 768>);
         if (stream_block == 512) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 512>);
@@ -909,7 +919,7 @@ extern "C" int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]) {
 
 extern "C" int rt_renderer_kernel_info(rt_renderer* r, uint32_t out[4]) {
     if (!r || !out) return rt_fail(RT_ERR_INVALID, "rt_renderer_kernel_info: null argument");
-    out[0] = r->variant;
+    out[0] = r->tol ? 5u + r->tol : r->variant;
     out[1] = (r->variant >= 2 && !r->scene.big) ? 1u : 0u;
     out[2] = r->variant >= 2 ? r->stream_block : 64u;
     out[3] = r->variant >= 2 ? r->stream_blocks_per_cu : 0u;

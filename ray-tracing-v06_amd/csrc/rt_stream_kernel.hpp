@@ -285,7 +285,8 @@ __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const
 // BIG: the records stay in global memory / L2 (the image does not fit the LDS); WIDE: 32-bit references (a BIG world with 2^14
 //      inner nodes or 2^15 leaf codes or more) — a BIG world whose references fit 16 bits keeps the narrow encoding, which halves
 //      the per-lane stacks and leaves that much more of the LDS for the top of the tree.
-template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false, bool WIDE = BIG>
+// TOL (variants 6 / 7, opt-in measurement of the tolerance-mode box test, NOT bit-exact): 1 = (b - o) * RN(1/d), 2 = fma(b, RN(1/d), -o * RN(1/d)).
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false, bool WIDE = BIG, int TOL = 0>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -380,7 +381,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
             inv_d = mk3(rcp_exact_regular(ray.d.x), rcp_exact_regular(ray.d.y), rcp_exact_regular(ray.d.z)); /* used by regular rays only */ \
-            if (FAST_BVH) inv_lo = mk3(rcp_low_word(ray.d.x, inv_d.x), rcp_low_word(ray.d.y, inv_d.y), rcp_low_word(ray.d.z, inv_d.z)); \
+            if (FAST_BVH && TOL != 2) inv_lo = mk3(rcp_low_word(ray.d.x, inv_d.x), rcp_low_word(ray.d.y, inv_d.y), rcp_low_word(ray.d.z, inv_d.z)); \
+            if (FAST_BVH && TOL == 2) inv_lo = mk3(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z); /* tolerance form 2: -o / d, per ray */ \
             const uint32_t km_ = (regular && FAST_BVH) ? 4u : 0u;          \
             kx = (__float_as_uint(ray.d.x) >> 29) & km_;                   \
             ky = (__float_as_uint(ray.d.y) >> 29) & km_;                   \
@@ -443,8 +445,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
                         const uint32_t left_idx = nd.left, right_idx = nd.right;
                         float tl, tr;
-                        const bool hl = slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
-                        const bool hr = slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
+                        const bool hl = TOL == 2 ? slab_near_far_tolerant2(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, inv_d, inv_lo, rec_t, tl)
+                                      : TOL == 1 ? slab_near_far_tolerant1(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl)
+                                                 : slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
+                        const bool hr = TOL == 2 ? slab_near_far_tolerant2(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, inv_d, inv_lo, rec_t, tr)
+                                      : TOL == 1 ? slab_near_far_tolerant1(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr)
+                                                 : slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
                         // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".

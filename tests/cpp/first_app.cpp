@@ -8,7 +8,7 @@
 // one rt_scene_book2_moving() builds — tests/test_cpp_api.py checks that bit for bit.
 //
 //   first_app flatten                     print a checksum of the flattened world (no GPU needed)
-//   first_app render W H SPP DEPTH [ppm]  render, print a checksum of the float framebuffer, write a PPM
+//   first_app render W H SPP DEPTH [ppm|f32]  render, print a checksum of the float framebuffer, write a PPM (or, *.f32, the raw floats)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -151,7 +151,15 @@ int main(int argc, char** argv) {
             renderer.DownloadRenderbuffer(host_output_framebuffer.data());
             std::printf("render %ux%u spp=%u depth=%u kernel_ms=%.3f fnv=%016llx\n", width, height, spp, depth, renderer.LastKernelMs(),
                         (unsigned long long)fnv1a(host_output_framebuffer.data(), host_output_framebuffer.size() * sizeof(glm::vec4)));
-            if (argc > 6 && std::string(argv[6]) != "--gpus" && std::string(argv[6]) != "-") write_renderbuffer(argv[6], width, height, host_output_framebuffer.data());
+            if (argc > 6 && std::string(argv[6]) != "--gpus" && std::string(argv[6]) != "-") {
+                std::string path = argv[6];
+                if (path.size() > 4 && path.substr(path.size() - 4) == ".f32") {   // the float framebuffer itself (row 0 = bottom), for the parity tests
+                    FILE* f = std::fopen(path.c_str(), "wb");
+                    if (!f) throw std::runtime_error("cannot write " + path);
+                    std::fwrite(host_output_framebuffer.data(), sizeof(glm::vec4), host_output_framebuffer.size(), f);
+                    std::fclose(f);
+                } else write_renderbuffer(path, width, height, host_output_framebuffer.data());
+            }
             delete cam;
         }
         delete scene_ptr;

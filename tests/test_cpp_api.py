@@ -57,6 +57,42 @@ def test_cpp_renderer_matches_c_abi_path_bit_for_bit():
     assert int(m[1], 16) == fnv1a([img.tobytes()])
 
 
+@pytest.mark.gpu
+def test_the_reference_apps_committed_frame_is_the_oracles_bit_for_bit(tmp_path):
+    """The ONE render configuration the reference commits (FirstApp.cpp:21-39): the live Book-2 moving-spheres scene under its BVH, 1280x720, 1 spp,
+    max_depth 4, MotionBlurCamera(lookfrom (13,2,3), lookat 0, up y, vfov 30, aspect 1280/720, t0 0.1, t1 1.0).  The full framebuffer is put
+    against the CPU oracle's render of that frame — through the Python mirror (api.py -> C ABI) AND through tests/cpp/first_app, the reference's
+    FirstApp flow compiled against include/rt06/rt06.hpp, with its default arguments (`render` alone = 1280 720 1 4)."""
+    import _oracle as O
+    from _common import bits_equal, mismatch_report
+    build_app()
+    W, H, spp, depth = 1280, 720, 1, 4
+    oscene = O.Scene.book2_moving(1984)
+    ocam = O.camera_motion((13, 2, 3), (0, 0, 0), (0, 1, 0), 30.0, W / H, 0.1, 1.0)
+    ref, _ = O.render(oscene.world, ocam, W, H, spp, depth, 1984, threads=min(16, os.cpu_count() or 1))
+    assert ref.shape == (H, W, 4) and np.all(ref[..., 3] == 1.0)
+    # (a) Python mirror
+    p = pkg()
+    s = p.Scene.book2_moving(1984)
+    cam = p.MotionBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 30.0, W / H, 0.1, 1.0)
+    r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, s.getWorldPtr())
+    r.Render()
+    img = r.DownloadRenderbuffer()
+    assert r.kernel_info()["variant"] >= 2   # the streaming kernel, not the baseline
+    r.close()
+    assert bits_equal(img, ref), mismatch_report(img, ref)
+    # (b) the C++ mirror's app with the reference's own defaults
+    raw = str(tmp_path / "frame.f32")
+    out = subprocess.check_output([APP, "render", str(W), str(H), str(spp), str(depth), raw], text=True)
+    m = re.search(r"render 1280x720 spp=1 depth=4 .*fnv=([0-9a-f]+)", out)
+    assert m, out
+    got = np.fromfile(raw, dtype=np.float32).reshape(H, W, 4)
+    assert bits_equal(got, ref), mismatch_report(got, ref)
+    out2 = subprocess.check_output([APP, "render"], text=True)   # no arguments: FirstApp.cpp's literals
+    m2 = re.search(r"render 1280x720 spp=1 depth=4 .*fnv=([0-9a-f]+)", out2)
+    assert m2 and m2[1] == m[1], out2
+
+
 CORNELL = os.path.join(ROOT, "tests", "cpp", "cornell_app")
 
 

@@ -31,3 +31,16 @@ def test_tile_layout_matches_the_library():
     from ray_tracing_v06_amd import multigpu
     assert multigpu.tile_layout(1200, 800, 8) == (150, 15000, 1875, 1875 * 256)
     assert multigpu.tile_layout(203, 117, 3) == (26, 390, 130, 130 * 256)
+
+
+def test_bench_without_a_launcher_starts_its_ranks_as_a_child_process():
+    """`python bench.py --gpus 2` with no launcher in the environment must not die in argument handling: it starts torch.distributed.run as a
+    child (before importing torch or loading the HIP library) and returns the child's exit code.  Here there is no GPU, so the ranks themselves
+    fail — loudly, with a non-zero code that bench.py relays; the GPU twin (tests/test_gpu_bench_line.py) checks the JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", "--width", "32",
+                          "--height", "16", "--spp", "1", "--steps", "1", "--warmup", "0"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert "starting 2 ranks" in res.stderr and "torch.distributed.run" in res.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
