@@ -38,7 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def BIT_EXACT(resolved_variant):
     """The streaming kernels (variants 2-5; 0 resolves to one of them) promise the oracle's bits.  Variant 1 (wave-per-pixel baseline: another
-    summation order) is held to north_star's tolerance |delta| < 1e-3 instead."""
+    summation order) and variant 6 (opt-in tolerance mode: products with the rounded reciprocal in the box tests) are held to north_star's
+    tolerance |delta| < 1e-3 instead; whether their frame was bit-identical anyway is reported."""
     return resolved_variant in (2, 3, 4, 5)
 
 
@@ -119,7 +120,7 @@ def host_cores():
     return n
 
 
-def profiled_counters(kernel_substr, workload, W, H, spp, depth):
+def profiled_counters(kernel_substr, workload, W, H, spp, depth, variant=0):
     """Per-launch hardware counters of the dominant kernel from the newest committed rocprofv3 summary of THIS workload at this
     frame size and depth (profiles/rNN_<name>_pmc_summary.csv, name = `bench` for the headline, else the workload; separate --pmc
     passes of this same command: tools/profile_round.sh, tools/profile_workload.sh).  A summary taken at another spp is scaled
@@ -132,15 +133,16 @@ def profiled_counters(kernel_substr, workload, W, H, spp, depth):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.csv")), reverse=True):
         name = os.path.basename(path).split("_", 1)[1][:-len("_pmc_summary.csv")]
         lines = open(path).read().splitlines()
-        stamp, cfg = None, legacy.get(name)
+        stamp, cfg, cfg_variant = None, legacy.get(name), 0
         while lines and lines[0].startswith("#"):
             if "csrc_sha256:" in lines[0]:
                 stamp = lines[0].split("csrc_sha256:")[1].strip()
             if "config:" in lines[0]:
                 f = lines[0].split("config:")[1].split()
                 cfg = (f[0], int(f[1]), int(f[2]), int(f[3]), int(f[4]))
+                cfg_variant = int(f[5].split("=")[1]) if len(f) > 5 and f[5].startswith("variant=") else 0   # the kernel variant it was taken with
             lines.pop(0)
-        if cfg is None or cfg[:3] != (workload, W, H) or cfg[4] != depth:
+        if cfg is None or cfg[:3] != (workload, W, H) or cfg[4] != depth or cfg_variant != variant:
             continue
         # (profiles are taken at an spp that fits ONE pass, so mean_per_dispatch is the count of the whole cfg[3]-spp frame)
         v = {}
@@ -435,8 +437,8 @@ def main():
             bytes_per_sample = 32.0 * counts["box_tests"] + 16.0 * counts["leaf_tests"] + 16.0 * counts["shaded_hits"] + 16.0 / spp
             launch_samples = total_samples / world_size
             dominant = "render_kernel_xchg" if kinfo["variant"] == 5 else "render_kernel_stream"
-            pmc, pmc_src, pmc_stamp, pmc_spp = (profiled_counters(dominant, args.workload, W, H, spp, args.depth)
-                                                if args.variant == 0 else (None, None, None, None))
+            # counters of the kernel variant that ran (a summary names the variant it was taken with; none = the default, 0)
+            pmc, pmc_src, pmc_stamp, pmc_spp = profiled_counters(dominant, args.workload, W, H, spp, args.depth, args.variant)
             if pmc is not None and world_size > 1:
                 # a rank's launch traces 1/N of the frame's samples (tiles interleave finely, so a shard is a fair sample of the frame): the
                 # committed whole-frame counters are scaled to the launch like samples_per_launch

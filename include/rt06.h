@@ -145,12 +145,12 @@ typedef struct rt_world_flat {
  *        (variant 0 / 2: its queue mode — a lane walks its whole trace with the queue when the trace begins; the framebuffer is
  *        the oracle's bit for bit) and on the baseline kernel (variant 1); the stack-walking variants 3-5 refuse it.  On the
  *        Book-1 final scene it saves 0.6 % of the box tests and costs 4.8 % more leaf tests (instrumented oracle); its frontier
- *        is one sorted list per ray, so it cannot share the wave-level hot loop: 1.29 against 5.6 Gsamples/s.
+ *        is one sorted list per ray, so it cannot share the wave-level hot loop: 1.29 against 5.6 Gsamples/s (EXPERIMENTS.md E2).
  * WIDE4: a 4-wide walk of the SAME binary tree (not in the reference, whose nodes are binary, BVH.cuh:16-25): a visit looks
  *        two levels down — up to four grandchild boxes, tested against rec.distance, nearest first, pushed far-to-near, culling at push time
  *        only (BVH.cu:87-96's rule generalised); the intermediate children's boxes are not tested.  Its 32 entries (at most 3 * ceil(depth / 2) + 1
  *        are needed) are checked like the queue's: RT_ERR_STACK at the next synchronising call.  Oracle twin: orc_world.traversal == 2.  Renders where the queue renders (streaming kernel's
- *        lane-walk mode bit-identical to the oracle, baseline kernel); measured next to the binary walk in DESIGN.md §14.               */
+ *        lane-walk mode bit-identical to the oracle, baseline kernel); measured next to the binary walk in EXPERIMENTS.md E3.               */
 enum { RT_TRAVERSAL_STACK = 0, RT_TRAVERSAL_QUEUE = 1, RT_TRAVERSAL_WIDE4 = 2 };
 
 enum {
@@ -280,8 +280,12 @@ typedef struct rt_render_config {
                                      dividing (BVH worlds with box coordinates in [2^-40, 2^40)), 4 = 3 + filtered predicates
                                      (experimental, reference features only), 5 = 3 with rays exchanged between tracer and
                                      shader waves of a workgroup through LDS rings (render_kernel_xchg; LDS-resident BVH worlds
-                                     of the reference's feature set; measured slower than 3, kept as an opt-in: DESIGN.md §14).
-                                     Same image bits for all >= 2; worlds beyond the LDS take the global-memory form of 2 / 3
+                                     of the reference's feature set; measured slower than 3, kept as an opt-in: EXPERIMENTS.md),
+                                     6 = 3 in TOLERANCE MODE (opt-in, never chosen by 0): the box tests' plane parameters are
+                                     (b - o) * RN(1/d) instead of aabb.cuh:30-31's quotients — inside BASELINE.json's |delta| < 1e-3,
+                                     NOT bit-exact by construction (measured: 0 differing pixels on BASELINE configs[1..3] at full
+                                     size, dominant kernel 1.15-1.26x faster); LDS-resident RT_WORLD_BVH worlds only.
+                                     Same image bits for 2..5; worlds beyond the LDS take the global-memory form of 2 / 3
                                      (rt_renderer_kernel_info).                                                                */
 } rt_render_config;
 
@@ -313,7 +317,7 @@ int rt_renderer_kernel_times(rt_renderer* r, uint32_t renders_back, float out_ms
  * default but at most 45 % of the HBM that is free when the renderer is created (RT06_PASS_BUDGET_BYTES to change it, RT06_PASS_SPP to
  * force the samples per pixel per pass: tests); if the device cannot provide the buffers the passes are halved until it can.           */
 int rt_renderer_pass_info(rt_renderer* r, uint64_t out[4]);
-/* Which kernel the renderer resolved to: out[0] = variant actually used (1..5), out[1] = 1 when the scene image is
+/* Which kernel the renderer resolved to: out[0] = variant actually used (1..6), out[1] = 1 when the scene image is
  * LDS-resident (0: baseline kernel, or a world too large for the LDS, served from global memory / L2 with 32-bit
  * references), out[2] = workgroup size, out[3] = workgroups per CU.                                              */
 int rt_renderer_kernel_info(rt_renderer* r, uint32_t out[4]);

@@ -117,21 +117,16 @@ __device__ __forceinline__ bool slab_near_far_regular(float nx, float ny, float 
     return tmin <= tmax && tmin < ray_max_dist && tmax > 0;
 }
 
-// TOLERANCE MODE (kernel variants 6 and 7, opt-in, NOT bit-exact): the same slab test with the quotients of aabb.cuh:30-31 replaced by
-// products with the rounded reciprocal — what every production ray tracer does, and what BASELINE.json's |delta| < 1e-3 would allow but the
-// oracle's bits do not.  Form 1: t = RN((b - o) * RN(1/d)) — two roundings instead of one, at most ~1 ulp off the true quotient.  Form 2:
-// t = fma(b, RN(1/d), RN(-o * RN(1/d))) — one instruction per plane; its error is relative to |o/d|, not to |t| (cancellation).
-__device__ __forceinline__ bool slab_near_far_tolerant1(float nx, float ny, float nz, float fx, float fy, float fz,
-                                                        const Ray& ray, f3 inv_d, float ray_max_dist, float& tmin_out) {
+// TOLERANCE MODE (kernel variant 6, opt-in, NOT bit-exact by construction): the same slab test with the quotients of aabb.cuh:30-31 replaced
+// by products with the correctly rounded reciprocal, t = RN((b - o) * RN(1/d)) — two roundings instead of one, at most ~1 ulp off the true quotient,
+// and still a monotone function of the plane offset for a given ray (so planes that two boxes share still tie exactly).  What BASELINE.json's
+// |delta| < 1e-3 allows and the oracle's bits do not promise.  Measured (round 4, EXPERIMENTS.md): 24 instead of 60 instructions for the twelve
+// plane parameters of a visit, the dominant kernel 1.26x / 1.23x / 1.15x faster on BASELINE configs[1..3], and 0 differing pixels on every
+// full-size frame; the one-instruction form fma(b, RN(1/d), -o * RN(1/d)) moved pixels by up to 0.08 and was deleted.
+__device__ __forceinline__ bool slab_near_far_tolerant(float nx, float ny, float nz, float fx, float fy, float fz,
+                                                       const Ray& ray, f3 inv_d, float ray_max_dist, float& tmin_out) {
     const float tmin = fmaxf(fmaxf((nx - ray.o.x) * inv_d.x, (ny - ray.o.y) * inv_d.y), (nz - ray.o.z) * inv_d.z);
     const float tmax = fminf(fminf((fx - ray.o.x) * inv_d.x, (fy - ray.o.y) * inv_d.y), (fz - ray.o.z) * inv_d.z);
-    tmin_out = tmin;
-    return tmin <= tmax && tmin < ray_max_dist && tmax > 0;
-}
-__device__ __forceinline__ bool slab_near_far_tolerant2(float nx, float ny, float nz, float fx, float fy, float fz,
-                                                        f3 inv_d, f3 neg_o_inv_d, float ray_max_dist, float& tmin_out) {
-    const float tmin = fmaxf(fmaxf(__builtin_fmaf(nx, inv_d.x, neg_o_inv_d.x), __builtin_fmaf(ny, inv_d.y, neg_o_inv_d.y)), __builtin_fmaf(nz, inv_d.z, neg_o_inv_d.z));
-    const float tmax = fminf(fminf(__builtin_fmaf(fx, inv_d.x, neg_o_inv_d.x), __builtin_fmaf(fy, inv_d.y, neg_o_inv_d.y)), __builtin_fmaf(fz, inv_d.z, neg_o_inv_d.z));
     tmin_out = tmin;
     return tmin <= tmax && tmin < ray_max_dist && tmax > 0;
 }

@@ -10,14 +10,7 @@
 #include "rt06.h"
 #include "rt_device_funcs.hpp"
 #include "rt_internal.hpp"
-
-// Pixel ownership.  The frame is cut into 8x8 tiles (row-major tile order); tile t belongs to rank
-// t % world_size.  A rank's pixels are enumerated tile-major: L = local_tile * 64 + (py * 8 + px).
-struct TileMap {
-    uint32_t width, height, tiles_x, n_tiles;
-    uint32_t rank, world_size, n_local_tiles;
-    uint32_t direct;  // 1: write row-major at gid (single GPU); 0: write the compact shard at L
-};
+#include "rt_layout.hpp"
 
 struct RenderParams {
     uint32_t width, height, spp, max_depth;

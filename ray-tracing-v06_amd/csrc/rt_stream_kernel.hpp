@@ -38,76 +38,19 @@
 #include "rt_device_funcs.hpp"
 #include "rt_fastdiv.hpp"
 #include "rt_internal.hpp"
+#include "rt_layout.hpp"
 #include "rt_render_kernels.hpp"
 
 #define RT_WORLD_BVH_QUEUE 3     // internal WORLD mode of render_kernel_stream: an RT_WORLD_BVH world walked by each lane on its own — the distance-sorted queue (RT_TRAVERSAL_QUEUE) or the 4-wide walk (RT_TRAVERSAL_WIDE4)
-#define RT_STREAM_BLOCK 768      // default workgroup: 12 wavefronts share one LDS copy of the scene; 2 workgroups per CU
 #define RT_CHUNK_MAX 768u        // sample indices a wave pulls per atomic (the host shrinks it for small frames / shards); 768 measured 0.35 ms ahead of 1024 and of 512 on config 2
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
 #define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
 #define RT_SHADE_MIN 56          // run the shade/regenerate phase once this many lanes wait for it
 #define RT_LEAF_MIN 4            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
-// Wide node, 19 dwords (76 B): both child boxes + both child references.
-//   dwords 3*(3*side + axis) .. +2 = (min, max, min) of that axis of the left (side 0) / right (side 1) child box;
-//   dword 18 = left reference | right reference << 16.
-// The (min, max, min) triple lets a lane read its (near, far) plane pair of an axis as two CONSECUTIVE dwords at
-// offset 0 (direction >= 0: near = min) or 4 bytes (direction < 0: near = max), i.e. the per-axis min/max of the
-// slab test (aabb.cuh:34-39) becomes a per-ray address offset instead of 12 v_min/v_max per visit — on gfx950 min,
-// max, compares and selects issue at half the rate of add/mul/fma (tools/bench_valu_issue.hip).  The odd stride
-// also spreads the rows of different nodes over all LDS banks.
-// A reference is 16 bits wide (an LDS-resident scene has < 2^15 inner nodes and leaf codes):
-//   bit 15 clear: wide-node index;  bit 15 set: leaf, code = ref & 0x7fff = prim * 2 + is_moving.
-// The same encoding travels through the per-lane LDS stack as 16-bit entries.
-#define RT_REF_LEAF 0x8000u
-#define RT_REF_IRR 0x4000u   // see FAST_BVH in render_kernel_stream
-#define RT_MAT_INDEX_MASK 0x0fffffffu  // matbits: index (28 bits) | moving << 28 | type << 29
-#define RT_NODE_DWORDS 19u
-#define RT_NODE_BYTES (RT_NODE_DWORDS * 4u)
-#define RT_NODE_REFS 18u
-// BIG scenes (the image does not fit the LDS, or has 2^14 inner nodes / 2^15 leaf codes or more): the records are read
-// from global memory (they stay L2-resident) and references are 32 bits wide (bit 31 marks a leaf, bit 30 a ray outside
-// the fast class); the per-lane stacks (32-bit entries) are all that lives in the LDS.  That path is bound by the L1's
-// tag-lookup rate — 64 lanes reading 64 different nodes cost ~20 lookups per load instruction (PMC) — not by the vector
-// issue, so its wide node is ONE 64-byte line read with four 16-byte loads, [lmin.xyz lmax.x | lmax.yz rmin.xy |
-// rmin.z rmax.xyz | left, right, -, -], and near / far planes are picked with selects instead of by address.
-#define RT_REF_LEAF_BIG 0x80000000u
-#define RT_REF_IRR_BIG 0x40000000u
-#ifdef RT_BIG_TRIPLES   // experiment: the LDS image's (min, max, min) triples in global memory too — (near, far) pairs by address, 80-byte nodes
-#define RT_NODE_DWORDS_BIG 20u
-#else
-#define RT_NODE_DWORDS_BIG 16u
-#endif
-// number of 16-B units the node region of `n` wide nodes occupies in the blob
-#define RT_NODES_VEC4(n, big) (((n) * ((big) ? RT_NODE_DWORDS_BIG : RT_NODE_DWORDS) + 3u) / 4u)
-
-// LDS image, in 16-B units:  [wide nodes (RT_NODE_DWORDS dwords each, region rounded up) | spheres (c0, r) | extra (c1, matbits) | mats16 (albedo, param) |
-//                              (padding to a 64-byte boundary) quads (4 each: Q,D | u,v.x | v.yz,n.xy | n.z,w) | quad shade records (normal, matbits)],   matbits = material index | moving << 28 | type << 29
-struct PackedSceneRef {
-    const uint4* blob;
-    uint32_t blob_vec4;      // number of 16-B units to stage into LDS
-    uint32_t off_spheres;
-    uint32_t off_extra;
-    uint32_t off_mats;
-    uint32_t off_quads;
-    uint32_t sphere_codes;   // leaf codes below this are spheres (prim * 2 + is_moving); code - sphere_codes is a quad index
-    uint32_t background;     // 0 = reference sky gradient, 1 = background_color
-    float background_color[3];
-    uint32_t root_ref;
-    float root_min[3], root_max[3];
-    uint32_t stack_cap;      // entries per lane
-    uint32_t n_inner, n_codes, n_prims, n_quads;
-    uint32_t n_top;          // BIG: the first n_top wide nodes (breadth-first order = the top of the tree) are staged in the LDS
-    const rt_material* mats; // full 32-B records in global memory (second colour of a checker material)
-    const rt_perlin* perlin; // EXT: noise tables / image of the two textured materials (global memory), or null
-    const uint8_t* image;
-    uint32_t image_w, image_h;
-};
-
 // A primary-ray record is read exactly once: a non-temporal load, so that this 23 GB stream does not push the partially written lines of
 // the sample buffer out of the L2 before their neighbours arrive.  Measured (config 2, round 3): HBM write traffic of the kernel
-// 9.79 GB -> 6.63 GB for 5.76 GB of samples (1.70x -> 1.15x), same time.  -DRT_PLAIN_PRIMARY = the plain loads of rounds 1-2.
-#ifndef RT_PLAIN_PRIMARY
+// 9.79 GB -> 6.63 GB for 5.76 GB of samples (1.70x -> 1.15x), same time (EXPERIMENTS.md).
 typedef float rt_nt_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rt_nt_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 rt_load_once(const float4* p) {
@@ -119,24 +62,14 @@ __device__ __forceinline__ uint4 rt_load_once(const uint4* p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 #define RT_LOAD_ONCE(ptr) rt_load_once(ptr)
-#else
-#define RT_LOAD_ONCE(ptr) (*(ptr))
-#endif
 // The generator's stores and the resolve kernel's loads are streams too (written once / read once): non-temporal, -0.13 ms per config-2 frame
-// (primary 4.03 -> 3.94 ms, resolve 0.99 -> 0.95 ms; -DRT_PLAIN_SIDE = plain accesses).
-#ifndef RT_PLAIN_SIDE
+// (primary 4.03 -> 3.94 ms, resolve 0.99 -> 0.95 ms).
 typedef float rt_nts_f4 __attribute__((ext_vector_type(4)));
 typedef uint32_t rt_nts_u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void rt_store_stream(float4* p, float4 v) { rt_nts_f4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<rt_nts_f4*>(p)); }
 __device__ __forceinline__ void rt_store_stream(uint4* p, uint4 v) { rt_nts_u4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<rt_nts_u4*>(p)); }
 __device__ __forceinline__ float rt_load_stream(const float* p) { return __builtin_nontemporal_load(p); }
-#else
-__device__ __forceinline__ void rt_store_stream(float4* p, float4 v) { *p = v; }
-__device__ __forceinline__ void rt_store_stream(uint4* p, uint4 v) { *p = v; }
-__device__ __forceinline__ float rt_load_stream(const float* p) { return *p; }
-#endif
 
-#ifndef RT_SAMPLE16
 #define RT_SAMPLE_BYTES 12u
 __device__ __forceinline__ void store_sample(float4* samples, uint32_t n, float x, float y, float z) {
     float* o = reinterpret_cast<float*>(samples) + (size_t)n * 3u;
@@ -146,11 +79,6 @@ __device__ __forceinline__ f3 load_sample(const float4* samples, size_t n) {
     const float* q = reinterpret_cast<const float*>(samples) + n * 3u;
     return mk3(rt_load_stream(q), rt_load_stream(q + 1), rt_load_stream(q + 2));
 }
-#else
-#define RT_SAMPLE_BYTES 16u
-__device__ __forceinline__ void store_sample(float4* samples, uint32_t n, float x, float y, float z) { samples[n] = make_float4(x, y, z, 0.0f); }
-__device__ __forceinline__ f3 load_sample(const float4* samples, size_t n) { const float4 v = samples[n]; return mk3(v.x, v.y, v.z); }
-#endif
 
 struct StreamParams {
     uint32_t width, height, spp, max_depth;
@@ -163,8 +91,8 @@ struct StreamParams {
     uint32_t total;          // n_local_pixels * pass_spp
     uint32_t inner_keep, shade_min, leaf_min;
     uint32_t chunk;          // sample indices per work-queue fetch
-    float4* samples;         // [n_local_pixels/64][pass_spp][64] radiance, 12 bytes per sample index n (one global_store_dwordx3); declared float4*
-                             // for the -DRT_SAMPLE16 measurement build (16-byte slots: measured slower and MORE HBM write traffic)
+    float4* samples;         // [n_local_pixels/64][pass_spp][64] radiance, RT_SAMPLE_BYTES = 12 bytes per sample index n (one global_store_dwordx3;
+                             // 16-byte slots were measured slower and MORE HBM write traffic: EXPERIMENTS.md)
     // primary rays of the pass, written by primary_rays_kernel and consumed by sample regeneration, indexed by n:
     float4* prim_o;          // (ray origin, ray time)
     float4* prim_d;          // (ray direction, -)
@@ -213,20 +141,6 @@ template <bool BIG>
 __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const uint4* top, uint32_t n_top, uint32_t idx,
                                                         uint32_t kx, uint32_t ky, uint32_t kz) {
     WideNodeData n;
-#ifdef RT_BIG_TRIPLES
-    if (BIG) {
-        const uint32_t nb = idx * (RT_NODE_DWORDS_BIG * 4u);
-        const float* px = reinterpret_cast<const float*>(nodes + (nb + kx));
-        const float* py = reinterpret_cast<const float*>(nodes + (nb + ky));
-        const float* pz = reinterpret_cast<const float*>(nodes + (nb + kz));
-        n.lnx = px[0]; n.lfx = px[1]; n.rnx = px[9]; n.rfx = px[10];
-        n.lny = py[3]; n.lfy = py[4]; n.rny = py[12]; n.rfy = py[13];
-        n.lnz = pz[6]; n.lfz = pz[7]; n.rnz = pz[15]; n.rfz = pz[16];
-        const uint2 refs = *reinterpret_cast<const uint2*>(nodes + nb + 72u);
-        n.left = refs.x; n.right = refs.y;
-        return n;
-    }
-#endif
     if (BIG) {
         float4 a, b, c;
         uint4 r;
@@ -285,8 +199,9 @@ __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const
 // BIG: the records stay in global memory / L2 (the image does not fit the LDS); WIDE: 32-bit references (a BIG world with 2^14
 //      inner nodes or 2^15 leaf codes or more) — a BIG world whose references fit 16 bits keeps the narrow encoding, which halves
 //      the per-lane stacks and leaves that much more of the LDS for the top of the tree.
-// TOL (variants 6 / 7, opt-in measurement of the tolerance-mode box test, NOT bit-exact): 1 = (b - o) * RN(1/d), 2 = fma(b, RN(1/d), -o * RN(1/d)).
-template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false, bool WIDE = BIG, int TOL = 0>
+// TOL (variant 6, opt-in): the hot loop's plane parameters are (b - o) * RN(1/d) instead of the exact quotients — inside north_star's |delta| < 1e-3,
+//      not bit-exact by construction (rt_fastdiv.hpp: slab_near_far_tolerant).  LDS-resident RT_WORLD_BVH worlds only.
+template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false, bool WIDE = BIG, bool TOL = false>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];
     const uint32_t tid = threadIdx.x;
@@ -381,8 +296,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         if (!EXACT) {                                                      \
             regular = ray_is_regular(ray);                                 \
             inv_d = mk3(rcp_exact_regular(ray.d.x), rcp_exact_regular(ray.d.y), rcp_exact_regular(ray.d.z)); /* used by regular rays only */ \
-            if (FAST_BVH && TOL != 2) inv_lo = mk3(rcp_low_word(ray.d.x, inv_d.x), rcp_low_word(ray.d.y, inv_d.y), rcp_low_word(ray.d.z, inv_d.z)); \
-            if (FAST_BVH && TOL == 2) inv_lo = mk3(-ray.o.x * inv_d.x, -ray.o.y * inv_d.y, -ray.o.z * inv_d.z); /* tolerance form 2: -o / d, per ray */ \
+            if (FAST_BVH && !TOL) inv_lo = mk3(rcp_low_word(ray.d.x, inv_d.x), rcp_low_word(ray.d.y, inv_d.y), rcp_low_word(ray.d.z, inv_d.z)); \
             const uint32_t km_ = (regular && FAST_BVH) ? 4u : 0u;          \
             kx = (__float_as_uint(ray.d.x) >> 29) & km_;                   \
             ky = (__float_as_uint(ray.d.y) >> 29) & km_;                   \
@@ -439,39 +353,23 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 const uint32_t keep_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pool_dry ? 1u : p.inner_keep));
                 do {
                     if (at_inner) {
-#ifdef RT_BRANCHLESS_STACK
-                        const ref_t top_ = *(sp - 64);
-#endif
                         const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
                         const uint32_t left_idx = nd.left, right_idx = nd.right;
                         float tl, tr;
-                        const bool hl = TOL == 2 ? slab_near_far_tolerant2(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, inv_d, inv_lo, rec_t, tl)
-                                      : TOL == 1 ? slab_near_far_tolerant1(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl)
-                                                 : slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
-                        const bool hr = TOL == 2 ? slab_near_far_tolerant2(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, inv_d, inv_lo, rec_t, tr)
-                                      : TOL == 1 ? slab_near_far_tolerant1(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr)
-                                                 : slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
+                        const bool hl = TOL ? slab_near_far_tolerant(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl)
+                                            : slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
+                        const bool hr = TOL ? slab_near_far_tolerant(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr)
+                                            : slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
                         // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".
                         const bool go_right = hr && (!hl || tl > tr);
-#ifdef RT_BRANCHLESS_STACK
-                        // experiment: no exec-mask manipulation for push / pop (scalar instructions are not free on gfx950):
-                        // the far child is written unconditionally into the free slot (harmless unless both boxes are hit)
-                        // and the entry below the top was read speculatively together with the node
-                        *sp = (ref_t)(go_right ? left_idx : right_idx);
-                        const bool both = hl && hr, none = !(hl || hr);
-                        cur = none ? (uint32_t)top_ : (go_right ? right_idx : left_idx);
-                        sp += both ? 64 : 0;
-                        sp -= none ? 64 : 0;
-#else
                         if (hl && hr) {
                             *sp = (ref_t)(go_right ? left_idx : right_idx);
                             sp += 64;
                         }
                         cur = go_right ? right_idx : left_idx;
                         if (!(hl || hr)) RT_POP();
-#endif
 #ifdef RT_TRACE_HIST
                         tr_steps_++;
 #endif

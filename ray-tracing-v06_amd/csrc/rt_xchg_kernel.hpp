@@ -42,10 +42,8 @@
 #pragma once
 #include "rt_stream_kernel.hpp"
 
-#define RT_XCHG_BLOCK 768
 #define RT_XCHG_SPIN_LIMIT (1u << 16)   // rounds of s_sleep + one LDS read (~400 cycles): ~10 ms, then the error flag
 #define RT_XCHG_IDLE_LIMIT (1u << 19)   // idle rounds of a wave that waits for the other role (~600 cycles each): ~0.1 s
-#define RT_XCHG_DEBUG_WORDS 16u         // per wave, written behind the error flag when the kernel gives up
 
 struct XchgParams {
     StreamParams s;           // scene image, pass, primary rays, sample buffer, work counter: as for render_kernel_stream
@@ -638,7 +636,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_xchg(XchgPar
                 const uint64_t m_ray = __ballot(state == S_RAY);
                 const uint32_t n_ray = (uint32_t)__popcll(m_ray);
                 const uint32_t rank = lane_rank(m_ray);
-                uint32_t pushed = 0, spins = 0;
+                uint32_t pushed = 0, spins = 0, cas_lost = 0;
                 uint64_t pw = n_ray != 0u ? xc_word(ring_word) : 0ull;
                 while (pushed < n_ray) {
                     const uint32_t tq_h = XC_TQ_H(pw), tq_t = XC_TQ_T(pw);
@@ -659,7 +657,19 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_xchg(XchgPar
                     uint32_t have = 0;
                     if (mine) have = xc_ld(tq_seq + slot);
                     const uint64_t found = xc_cas(ring_word, pw, xc_pack(XC_SQ_H(pw), XC_SQ_T(pw), tq_h, tq_t + g), lane);
-                    if (found != pw) { pw = found; continue; }
+                    if (found != pw) {
+                        // a lost compare-and-swap is retried with the word it found — a bounded number of times in a row like every other wait of
+                        // this kernel (a corrupted `found` once made exactly this loop spin for ever: the readfirstlane sign extension, EXPERIMENTS.md)
+                        if (++cas_lost > RT_XCHG_IDLE_LIMIT || xc_ld(ctrl + XC_ERR) != 0u) {
+                            xc_st(ctrl + XC_ERR, 5u);
+                            *xp.error_flag = 5u;
+                            xc_dump(xp.error_flag, 5u, wave, lane, ctrl, n_ray, pushed, cas_lost, 1u);
+                            break;
+                        }
+                        pw = found;
+                        continue;
+                    }
+                    cas_lost = 0;
                     if (mine) {
                         xc_wait_seq(tq_seq + slot, have, pos, ctrl, xp.error_flag);
                         XC_ORDER_ACQUIRE();

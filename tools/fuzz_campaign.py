@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=100)
 ap.add_argument("--first", type=int, default=0)
 ap.add_argument("--variants", action="store_true", help="pick a random kernel variant (0..5) per world — variant 5 (ray exchange) with random roles / thresholds / ring pairs —, now and then a forced multi-pass cut; unsupported combinations are skipped")
+ap.add_argument("--force-variant", type=int, default=None, help="render every world with this kernel variant; 6 (tolerance mode) is held to |delta| < 1e-3 and its differing frames are counted, not failed")
 args = ap.parse_args()
 p = G.load_package()
 
@@ -97,6 +98,8 @@ for seed in range(args.first, args.first + args.seeds):
         cam = p.MotionBlurCamera(eye, (0, 0, 0), (0, 1, 0), float(rng.uniform(20, 100)), W / H, 0.0, 1.0)
     w = s.getWorldPtr()
     variant = int(rng.integers(0, 6)) if args.variants else 0
+    if args.force_variant is not None:
+        variant = args.force_variant
     for k in ("RT06_XCHG", "RT06_PASS_SPP"):
         os.environ.pop(k, None)
     if args.variants and variant == 5:   # tracers, extra rays, exchange / shade thresholds, patience, priority, keep, ring pairs
@@ -128,7 +131,13 @@ for seed in range(args.first, args.first + args.seeds):
     stats["baseline" if info["variant"] == 1 else ("xchg" if info["variant"] == 5 else ("lds" if info["lds_resident"] else "global"))] += 1
     if w.traversal:
         stats[("queue", "wide4")[w.traversal - 1]] = stats.get(("queue", "wide4")[w.traversal - 1], 0) + 1
-    if info["variant"] == 1:
+    if info["variant"] == 6:   # tolerance mode: inside |delta| < 1e-3; frames that are not the oracle's bits are counted
+        same = bits_equal(img, ref)
+        stats["tol_frames_not_bit_identical"] = stats.get("tol_frames_not_bit_identical", 0) + (0 if same else 1)
+        dmax = 0.0 if same else float(np.nanmax(np.abs(img - ref)))
+        stats["tol_max_abs_delta"] = max(stats.get("tol_max_abs_delta", 0.0), dmax)
+        ok = np.array_equal(np.isnan(img), np.isnan(ref)) and dmax < 1e-3
+    elif info["variant"] == 1:
         ok = np.array_equal(np.isnan(img), np.isnan(ref)) and float(np.nanmax(np.abs(img - ref))) <= 1e-5 * max(1.0, float(np.nanmax(ref)))
     else:
         ok = bits_equal(img, ref)
