@@ -102,11 +102,6 @@ struct rt_renderer {
         bool can_stream = scene.has_packed;
         if (can_stream) {
             stream_block = RT_STREAM_BLOCK;
-            if (const char* env = std::getenv("RT06_BLOCK")) {  // occupancy experiments: 512 / 768 / 1024 threads — instantiated for the
-                int v = std::atoi(env);                         // reference-feature BVH kernel (variant 3) only; every other kernel is 768
-                const bool has_instances = !scene.big && !scene.extended && scene.dw.kind == RT_WORLD_BVH && scene.regular_boxes && (cfg.variant == 0 || cfg.variant == 3);
-                if ((v == 512 || v == 768 || v == 1024) && has_instances) stream_block = (uint32_t)v;
-            }
             if (scene.big) {  // the per-lane stacks (32-bit entries) and, in what two workgroups per CU leave free, the top of the tree
                 stream_block = RT_STREAM_BLOCK;
                 const uint32_t stacks = (stream_block * scene.packed.stack_cap * (scene.wide ? 4u : 2u) + 63u) & ~63u;
@@ -118,8 +113,7 @@ struct rt_renderer {
                 n_top = top_bytes / (RT_NODE_DWORDS_BIG * 4u);
                 stream_lds_bytes = top_bytes + stacks;
             } else {
-                // (1024-thread workgroups keep the material records in global memory: rt_stream_kernel.hpp MATS_GLOBAL)
-                stream_lds_bytes = (stream_block == 1024u ? scene.packed.off_mats : scene.packed.blob_vec4) * 16u + stream_block * scene.packed.stack_cap * 2u;
+                stream_lds_bytes = scene.packed.blob_vec4 * 16u + stream_block * scene.packed.stack_cap * 2u;
                 stream_lds_bytes = (stream_lds_bytes + 15u) & ~15u;
             }
             if (stream_lds_bytes > lds_per_cu) can_stream = false;
@@ -148,7 +142,7 @@ struct rt_renderer {
         variant = want;
         if (want_tol) {
             // (the global-memory form gains 8 % from it, below the 15 % it would have to: EXPERIMENTS.md)
-            if (scene.big || stream_block != RT_STREAM_BLOCK)
+            if (scene.big)
                 return rt_fail(RT_ERR_INVALID, "kernel variant 6 (tolerance-mode box test) is instantiated for LDS-resident RT_WORLD_BVH worlds only: use variant 0");
             tol = true;
         }
@@ -285,8 +279,6 @@ struct rt_renderer {
         if (tol) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 0, false, false, true>);
         if (variant == 2) return reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768>);
         if (variant == 4) return reinterpret_cast<const void*>(&render_kernel_stream<false, true, 768>);
-        if (stream_block == 512) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 512>);
-        if (stream_block == 1024) return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 1024>);
         return reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768>);
     }
 

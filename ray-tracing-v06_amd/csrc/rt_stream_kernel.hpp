@@ -215,7 +215,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
     constexpr uint32_t K_OFF = WIDE ? 0xfffffffeu : 0x30000u, K_START = WIDE ? 0xffffffffu : 0x40000u;
     static_assert(BIG || !WIDE, "an LDS-resident image always has 16-bit references");
 
-    constexpr bool MATS_GLOBAL = !BIG && BLOCK == 1024;
     // ---- the scene: staged into the LDS with coalesced 16-B loads, or (BIG) left in global memory / L2 -------------
     const uint4* scene_base;
     if (BIG) {
@@ -223,20 +222,17 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         for (uint32_t i = tid; i < p.scene.n_top * (RT_NODE_DWORDS_BIG / 4u); i += BLOCK) lds[i] = p.scene.blob[i];   // the top of the tree
         __syncthreads();
     } else {
-        // 1024-thread workgroups (16 waves; two per CU = 8 waves per SIMD): their stacks leave no room for the 16-byte material records,
-        // which the shade phase then reads from global memory / L1 (one record per shaded hit)
-        const uint32_t staged = MATS_GLOBAL ? p.scene.off_mats : p.scene.blob_vec4;
-        for (uint32_t i = tid; i < staged; i += BLOCK) lds[i] = p.scene.blob[i];
+        for (uint32_t i = tid; i < p.scene.blob_vec4; i += BLOCK) lds[i] = p.scene.blob[i];
         __syncthreads();
         scene_base = lds;
     }
     const char* nodes = reinterpret_cast<const char*>(scene_base);
     const float4* spheres = reinterpret_cast<const float4*>(scene_base + p.scene.off_spheres);
     const float4* extra = reinterpret_cast<const float4*>(scene_base + p.scene.off_extra);
-    const float4* mats16 = MATS_GLOBAL ? reinterpret_cast<const float4*>(p.scene.blob + p.scene.off_mats) : reinterpret_cast<const float4*>(scene_base + p.scene.off_mats);
+    const float4* mats16 = reinterpret_cast<const float4*>(scene_base + p.scene.off_mats);
     const float4* quads = reinterpret_cast<const float4*>(scene_base + p.scene.off_quads);
     // per-lane traversal stack of references (16 bits, BIG: 32).  Entry k of this lane is stack[k * 64].
-    ref_t* stack = reinterpret_cast<ref_t*>(lds + (BIG ? p.scene.n_top * (RT_NODE_DWORDS_BIG / 4u) : (MATS_GLOBAL ? p.scene.off_mats : p.scene.blob_vec4))) + wave * 64u * p.scene.stack_cap + lane;
+    ref_t* stack = reinterpret_cast<ref_t*>(lds + (BIG ? p.scene.n_top * (RT_NODE_DWORDS_BIG / 4u) : p.scene.blob_vec4)) + wave * 64u * p.scene.stack_cap + lane;
 
     const f3 root_min = mk3(p.scene.root_min[0], p.scene.root_min[1], p.scene.root_min[2]);
     const f3 root_max = mk3(p.scene.root_max[0], p.scene.root_max[1], p.scene.root_max[2]);
