@@ -44,3 +44,12 @@ def test_bench_without_a_launcher_starts_its_ranks_as_a_child_process():
     import torch
     if not torch.cuda.is_available():
         assert res.returncode != 0 and not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_gather_of_tile_shards_with_eight_ranks():
+    """the rank count of the scaling run's last point (N = 8), on the CPU: eight gloo processes, one gather, the frame back bit for bit"""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "_dist_worker.py")]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]

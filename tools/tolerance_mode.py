@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """The tolerance-mode box test, measured once with a hard acceptance rule.
 
-Kernel variants 6 and 7 are variant 3 (the default streaming kernel) with the twelve exact quotients of a visit (aabb.cuh:30-31's divisions,
-recovered bit for bit in 4 instructions each) replaced by products with the rounded reciprocal: 6 = (b - o) * RN(1/d), 7 = fma(b, RN(1/d), -o * RN(1/d)).
-They are NOT bit-exact.  Per workload (BASELINE configs[1..4] at their own frame size; the spp is what the CPU oracle renders in about a minute, or
-the config's own when that fits) this prints: kernel ms (HIP events, mean of N renders) of variants 0 / 6 / 7, and — against the CPU oracle's full frame —
+Kernel variant 6 is variant 3 (the default streaming kernel) with the twelve exact quotients of a visit (aabb.cuh:30-31's divisions,
+recovered bit for bit in 4 instructions each) replaced by products with the rounded reciprocal, (b - o) * RN(1/d).  (Round 4 also measured the
+one-instruction form fma(b, RN(1/d), -o * RN(1/d)) as variant 7: it moved pixels by up to 0.08 and was deleted, EXPERIMENTS.md E4.)  Variant 6 is NOT
+bit-exact by construction.  Per workload (BASELINE configs[1..4] at their own frame size; the spp is what the CPU oracle renders in about a minute, or
+the config's own when that fits) this prints: kernel ms (HIP events, mean of N renders) of variants 0 / 6, and — against the CPU oracle's full frame —
 the number of pixels that differ and max |delta| per channel.  Accept (as a documented opt-in) only if max |delta| < 1e-3 on EVERY frame and the dominant
 kernel is >= 15 % faster; otherwise the code is deleted and the numbers stay in EXPERIMENTS.md.
 
@@ -47,8 +48,12 @@ def main():
         ref, _ = O.render(oscene.world, ocam, W, H, spp, depth, 1984, threads=cores)
         t_cpu = time.perf_counter() - t
         base_ms = None
-        for variant in (0, 6, 7):
-            r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, scene.getWorldPtr(), variant=variant)
+        for variant in (0, 6):
+            try:
+                r = p.Renderer.MakeRenderer(W, H, spp, depth, cam, scene.getWorldPtr(), variant=variant)
+            except p.capi.RtError as e:   # e.g. variant 6 on the global-memory form (measured +8 % in the acceptance run and not kept)
+                print(json.dumps({"workload": name, "variant": variant, "refused": str(e)[:160]}), flush=True)
+                continue
             r.Render()
             ts = []
             for _ in range(4):
