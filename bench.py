@@ -289,6 +289,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world_size} of the launcher")
     if args.same_device:
         local_rank = 0
+    n_visible = torch.cuda.device_count()   # (counting devices does not initialise the GPU on this image)
+    if n_visible and local_rank >= n_visible:
+        # a launcher that isolates the ranks (one visible device per process: HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES set per rank) hands
+        # every rank "device 0" of its own view; with fewer visible devices than ranks for any other reason RCCL itself refuses later
+        local_rank %= n_visible
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
@@ -426,7 +431,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.workload][8]}, {W}x{H}, {spp} spp, "
                                    f"max_depth {args.depth}, seed {args.seed}, {WORKLOADS[args.workload][9]}",
-                       "parallelism": f"tile-shard x{world_size} + 1 RCCL gather" if world_size > 1 else "single GPU",
+                       "parallelism": (f"tile-shard x{world_size} + 1 {'RCCL' if args.backend == 'nccl' else args.backend} gather" if world_size > 1 else "single GPU"),
                        "frames_in_flight": depth, "serial_render_ms_rank0": (None if serial_ms is None else round(serial_ms, 3)),
                        "kernel_variant": args.variant},
             "kernel_ms_per_step_rank0": round(kernel_ms, 3), "kernel_ms_source": kernel_ms_source + " (all kernels of a step)",
