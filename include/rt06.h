@@ -283,8 +283,10 @@ typedef struct rt_render_config {
                                      of the reference's feature set; measured slower than 3, kept as an opt-in: EXPERIMENTS.md),
                                      6 = 3 in TOLERANCE MODE (opt-in, never chosen by 0): the box tests' plane parameters are
                                      (b - o) * RN(1/d) instead of aabb.cuh:30-31's quotients — inside BASELINE.json's |delta| < 1e-3,
-                                     NOT bit-exact by construction (measured: 0 differing pixels on BASELINE configs[1..3] at full
-                                     size, dominant kernel 1.15-1.26x faster); LDS-resident RT_WORLD_BVH worlds only.
+                                     NOT bit-exact by construction (measured: 0 differing pixels on BASELINE configs[1..2] at full
+                                     size, dominant kernel 1.24-1.26x faster); LDS-resident RT_WORLD_BVH worlds of the reference's own
+                                     feature set only — worlds with quads / lights / media are refused (a quad's edges are its box's
+                                     edges: the Cornell box at 5000 spp left the tolerance in one pixel, EXPERIMENTS.md E4).
                                      Same image bits for 2..5; worlds beyond the LDS take the global-memory form of 2 / 3
                                      (rt_renderer_kernel_info).                                                                */
 } rt_render_config;

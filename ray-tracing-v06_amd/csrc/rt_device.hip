@@ -141,9 +141,11 @@ struct rt_renderer {
             return rt_fail(RT_ERR_INVALID, "kernel variants 3 and 4 need every box coordinate to be 0 or within [2^-40, 2^40)");
         variant = want;
         if (want_tol) {
-            // (the global-memory form gains 8 % from it, below the 15 % it would have to: EXPERIMENTS.md)
-            if (scene.big)
-                return rt_fail(RT_ERR_INVALID, "kernel variant 6 (tolerance-mode box test) is instantiated for LDS-resident RT_WORLD_BVH worlds only: use variant 0");
+            // Kept for the reference's own feature set only (spheres: a sphere touches its box at six points, so a box decision that flips by an ulp
+            // almost never meets a hit).  Worlds with quads are refused: a quad's edges ARE its box's edges, and the Cornell box at its own 5000 spp moved
+            // one pixel by 2.1e-3, outside the tolerance; the global-memory form gains 8 %, below the 15 % it would have to (EXPERIMENTS.md E4)
+            if (scene.big || scene.extended)
+                return rt_fail(RT_ERR_INVALID, "kernel variant 6 (tolerance-mode box test) is instantiated for LDS-resident RT_WORLD_BVH worlds of the reference's feature set only (spheres, the three scattering materials, the sky): use variant 0");
             tol = true;
         }
         if (variant == 5) {
@@ -265,9 +267,6 @@ struct rt_renderer {
         if (scene.dw.kind == RT_WORLD_LIST && scene.extended)
             return scene.textured ? reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST, 2>)
                                   : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_LIST, 1>);
-        if (scene.extended && tol)
-            return scene.textured ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 2, false, false, true>)
-                                  : reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 1, false, false, true>);
         if (scene.extended) {
             if (scene.textured) return fast ? reinterpret_cast<const void*>(&render_kernel_stream<false, false, 768, RT_WORLD_BVH, 2>)
                                             : reinterpret_cast<const void*>(&render_kernel_stream<true, false, 768, RT_WORLD_BVH, 2>);

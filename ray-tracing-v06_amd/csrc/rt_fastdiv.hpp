@@ -120,9 +120,10 @@ __device__ __forceinline__ bool slab_near_far_regular(float nx, float ny, float 
 // TOLERANCE MODE (kernel variant 6, opt-in, NOT bit-exact by construction): the same slab test with the quotients of aabb.cuh:30-31 replaced
 // by products with the correctly rounded reciprocal, t = RN((b - o) * RN(1/d)) — two roundings instead of one, at most ~1 ulp off the true quotient,
 // and still a monotone function of the plane offset for a given ray (so planes that two boxes share still tie exactly).  What BASELINE.json's
-// |delta| < 1e-3 allows and the oracle's bits do not promise.  Measured (round 4, EXPERIMENTS.md): 24 instead of 60 instructions for the twelve
-// plane parameters of a visit, the dominant kernel 1.26x / 1.23x / 1.15x faster on BASELINE configs[1..3], and 0 differing pixels on every
-// full-size frame; the one-instruction form fma(b, RN(1/d), -o * RN(1/d)) moved pixels by up to 0.08 and was deleted.
+// |delta| < 1e-3 allows and the oracle's bits do not promise.  Measured (round 4, EXPERIMENTS.md E4): 24 instead of 60 instructions for the twelve
+// plane parameters of a visit, the dominant kernel 1.26x / 1.24x faster on BASELINE configs[1..2] with 0 differing pixels on the full-size frames.
+// Sphere worlds only: with quads (whose edges coincide with their boxes' edges) the Cornell box at 5000 spp moved one pixel by 2.1e-3, so worlds
+// beyond the reference's feature set are refused; the one-instruction form fma(b, RN(1/d), -o * RN(1/d)) moved pixels by up to 0.08 and was deleted.
 __device__ __forceinline__ bool slab_near_far_tolerant(float nx, float ny, float nz, float fx, float fy, float fz,
                                                        const Ray& ray, f3 inv_d, float ray_max_dist, float& tmin_out) {
     const float tmin = fmaxf(fmaxf((nx - ray.o.x) * inv_d.x, (ny - ray.o.y) * inv_d.y), (nz - ray.o.z) * inv_d.z);

@@ -200,7 +200,7 @@ __device__ __forceinline__ WideNodeData fetch_wide_node(const char* nodes, const
 //      inner nodes or 2^15 leaf codes or more) — a BIG world whose references fit 16 bits keeps the narrow encoding, which halves
 //      the per-lane stacks and leaves that much more of the LDS for the top of the tree.
 // TOL (variant 6, opt-in): the hot loop's plane parameters are (b - o) * RN(1/d) instead of the exact quotients — inside north_star's |delta| < 1e-3,
-//      not bit-exact by construction (rt_fastdiv.hpp: slab_near_far_tolerant).  LDS-resident RT_WORLD_BVH worlds only.
+//      not bit-exact by construction (rt_fastdiv.hpp: slab_near_far_tolerant).  LDS-resident RT_WORLD_BVH worlds of the reference's feature set (EXT == 0) only.
 template <bool EXACT, bool FILTER, int BLOCK, int WORLD = RT_WORLD_BVH, int EXT = 0, bool BIG = false, bool WIDE = BIG, bool TOL = false>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(StreamParams p) {
     extern __shared__ uint4 lds[];

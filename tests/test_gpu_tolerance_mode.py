@@ -1,7 +1,8 @@
 """Kernel variant 6, the opt-in TOLERANCE MODE of the streaming kernel: the twelve plane parameters of a node visit are (b - o) * RN(1/d) instead of
 aabb.cuh:30-31's quotients (which the default kernel reproduces bit for bit).  Its contract is BASELINE.json's |delta| < 1e-3 per channel against
-the CPU oracle, not the oracle's bits; the default (variant 0) never resolves to it.  Round 4 measured it bit-identical on every full-size frame of
-BASELINE configs[1..3] (tools/tolerance_mode.py, EXPERIMENTS.md); here the tolerance is what is asserted and the bit-identity is only reported."""
+the CPU oracle, not the oracle's bits; the default (variant 0) never resolves to it and worlds beyond the reference's feature set (quads, lights, media) or beyond the LDS refuse it.  Round 4
+measured it bit-identical on the full-size frames of BASELINE configs[1..2] (tools/tolerance_mode.py, EXPERIMENTS.md E4); here the tolerance is what is
+asserted and the bit-identity is only reported."""
 import numpy as np
 import pytest
 
@@ -27,7 +28,7 @@ def O_cams():
     return _OCams
 
 
-@pytest.mark.parametrize("which,W,H,spp", [("book1_final", 300, 200, 16), ("book2_moving", 200, 200, 16), ("cornell_box", 150, 150, 32)])
+@pytest.mark.parametrize("which,W,H,spp", [("book1_final", 300, 200, 16), ("book2_moving", 200, 200, 16)])
 def test_tolerance_mode_is_inside_the_stated_tolerance(which, W, H, spp):
     p = pkg()
     scene, cam = config_scene(p, which), config_cameras(p, which, W, H)
@@ -53,5 +54,8 @@ def test_the_default_never_resolves_to_tolerance_mode_and_other_worlds_refuse_it
     big = config_scene(p, "book2_final")   # records in global memory: not instantiated (measured +8 %, below the acceptance bar)
     with pytest.raises(p.capi.RtError):
         p.Renderer.MakeRenderer(64, 48, 2, 8, config_cameras(p, "book2_final", 64, 48), big.getWorldPtr(), variant=6)
+    quads = config_scene(p, "cornell_box")   # quads: a quad's edges are its box's edges — the Cornell box at its own 5000 spp left the tolerance in one pixel
+    with pytest.raises(p.capi.RtError):
+        p.Renderer.MakeRenderer(64, 48, 2, 8, config_cameras(p, "cornell_box", 64, 48), quads.getWorldPtr(), variant=6)
     with pytest.raises(p.capi.RtError):
         p.Renderer.MakeRenderer(64, 48, 2, 8, cam, scene.getWorldPtr(), variant=7)
