@@ -481,14 +481,14 @@ class Renderer {
         rt06::check(rt_scene_get_flat(tmp.get(), &w), "rt_scene_get_flat");
     }
     static Renderer make(uint32_t w_, uint32_t h_, uint32_t spp, uint32_t depth, const rt_camera& cam, const Hittable* world, uint64_t seed, int device,
-                         uint32_t n_gpus) {
+                         uint32_t n_gpus, uint32_t variant) {
         if (!world) throw std::runtime_error("Renderer::MakeRenderer: null world");
         rt06::SceneBuilder tmp;
         rt_world_flat wf;
         flatten(world, tmp, wf);
         rt_render_config cfg{};
         cfg.width = w_; cfg.height = h_; cfg.samples_per_pixel = spp; cfg.max_depth = depth;
-        cfg.seed = seed; cfg.device = device; cfg.rank = 0; cfg.world_size = 1; cfg.variant = 0;
+        cfg.seed = seed; cfg.device = device; cfg.rank = 0; cfg.world_size = 1; cfg.variant = variant;
         M mm;
         mm.render_width = w_; mm.render_height = h_; mm.samples_per_pixel = spp; mm.max_depth = depth;
         if (n_gpus > 1) rt06::check(rt_multi_renderer_create(&cfg, &cam, &wf, n_gpus, nullptr, &mm.mr), "Renderer::MakeRenderer");
@@ -506,17 +506,23 @@ public:
     // The reference takes `const MotionBlurCamera*`; the other two camera types are accepted as well.
     // seed: the reference hard-codes 1984 (Renderer.cu:51).  n_gpus > 1: the frame is tile-sharded over GPUs 0 .. n_gpus-1 of the
     // node and gathered on GPU 0 with one RCCL exchange (rt_multi_renderer_*); the image is the same for every n_gpus.
+    // variant: rt_render_config::variant — 0 (default: the fastest kernel that renders the reference's bits); kToleranceMode opts a sphere world of the
+    // reference's feature set into box tests by reciprocal multiplication (inside |delta| < 1e-3, not bit-exact by construction, ~1.25x faster).
+    static constexpr uint32_t kToleranceMode = 6;
     static Renderer MakeRenderer(uint32_t render_width, uint32_t render_height, uint32_t samples_per_pixel, uint32_t max_depth,
-                                 const MotionBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1) {
-        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus);
+                                 const MotionBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1,
+                                 uint32_t variant = 0) {
+        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus, variant);
     }
     static Renderer MakeRenderer(uint32_t render_width, uint32_t render_height, uint32_t samples_per_pixel, uint32_t max_depth,
-                                 const DefocusBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1) {
-        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus);
+                                 const DefocusBlurCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1,
+                                 uint32_t variant = 0) {
+        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus, variant);
     }
     static Renderer MakeRenderer(uint32_t render_width, uint32_t render_height, uint32_t samples_per_pixel, uint32_t max_depth,
-                                 const PinholeCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1) {
-        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus);
+                                 const PinholeCamera* cam, const Hittable* d_world_ptr, uint64_t seed = 1984, int device = 0, uint32_t n_gpus = 1,
+                                 uint32_t variant = 0) {
+        return make(render_width, render_height, samples_per_pixel, max_depth, cam->cam, d_world_ptr, seed, device, n_gpus, variant);
     }
     void Render() {
         if (m.mr) rt06::check(rt_multi_renderer_render(m.mr), "Renderer::Render");

@@ -143,15 +143,17 @@ int main(int argc, char** argv) {
             float fov = 30.0f, aspect = width / (float)height;
             auto cam = new MotionBlurCamera(lookfrom, lookat, up, fov, aspect, 0.1f, 1.0f);
             // `first_app render W H spp depth out.ppm --gpus N`: tile-shard the frame over N GPUs, one RCCL gather (not in the reference)
-            uint32_t n_gpus = 1;
+            // `... --variant 6`: opt into the tolerance-mode kernel (Renderer::kToleranceMode; not in the reference)
+            uint32_t n_gpus = 1, variant = 0;
             for (int a = 2; a + 1 < argc; a++) if (std::string(argv[a]) == "--gpus") n_gpus = (uint32_t)std::atoi(argv[a + 1]);
-            Renderer renderer = Renderer::MakeRenderer(width, height, spp, depth, cam, scene_ptr->getWorldPtr(), 1984, 0, n_gpus);
+            for (int a = 2; a + 1 < argc; a++) if (std::string(argv[a]) == "--variant") variant = (uint32_t)std::atoi(argv[a + 1]);
+            Renderer renderer = Renderer::MakeRenderer(width, height, spp, depth, cam, scene_ptr->getWorldPtr(), 1984, 0, n_gpus, variant);
             std::vector<glm::vec4> host_output_framebuffer((size_t)width * height);
             renderer.Render();
             renderer.DownloadRenderbuffer(host_output_framebuffer.data());
             std::printf("render %ux%u spp=%u depth=%u kernel_ms=%.3f fnv=%016llx\n", width, height, spp, depth, renderer.LastKernelMs(),
                         (unsigned long long)fnv1a(host_output_framebuffer.data(), host_output_framebuffer.size() * sizeof(glm::vec4)));
-            if (argc > 6 && std::string(argv[6]) != "--gpus" && std::string(argv[6]) != "-") {
+            if (argc > 6 && std::string(argv[6]) != "--gpus" && std::string(argv[6]) != "--variant" && std::string(argv[6]) != "-") {
                 std::string path = argv[6];
                 if (path.size() > 4 && path.substr(path.size() - 4) == ".f32") {   // the float framebuffer itself (row 0 = bottom), for the parity tests
                     FILE* f = std::fopen(path.c_str(), "wb");

@@ -59,3 +59,21 @@ def test_the_default_never_resolves_to_tolerance_mode_and_other_worlds_refuse_it
         p.Renderer.MakeRenderer(64, 48, 2, 8, config_cameras(p, "cornell_box", 64, 48), quads.getWorldPtr(), variant=6)
     with pytest.raises(p.capi.RtError):
         p.Renderer.MakeRenderer(64, 48, 2, 8, cam, scene.getWorldPtr(), variant=7)
+
+
+def test_cpp_mirror_can_opt_into_tolerance_mode(tmp_path):
+    """Renderer::MakeRenderer(..., variant = Renderer::kToleranceMode) of include/rt06/rt06.hpp, through tests/cpp/first_app (the reference's FirstApp flow:
+    live Book-2 moving scene, MotionBlurCamera vfov 30, shutter 0.1..1): inside the tolerance against the oracle's frame"""
+    import os
+    import subprocess
+    from _common import ROOT
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp")])
+    W, H, spp, depth = 320, 180, 8, 50
+    raw = str(tmp_path / "frame.f32")
+    subprocess.check_call([os.path.join(ROOT, "tests", "cpp", "first_app"), "render", str(W), str(H), str(spp), str(depth), raw, "--variant", "6"], stdout=subprocess.DEVNULL)
+    got = np.fromfile(raw, dtype=np.float32).reshape(H, W, 4)
+    scene = O.Scene.book2_moving(1984)
+    ref, _ = O.render(scene.world, O.camera_motion((13, 2, 3), (0, 0, 0), (0, 1, 0), 30.0, W / H, 0.1, 1.0), W, H, spp, depth)
+    d = np.abs(got - ref)
+    d[np.isnan(d)] = 0.0
+    assert np.array_equal(np.isnan(got), np.isnan(ref)) and d.max() < 1e-3

@@ -28,6 +28,8 @@ def image(h, w, rng):
 def make_world(rng):
     s = p.Scene()
     kinds = rng.integers(0, 4)   # 0 spheres only (reference features), 1 + quads/lights/background, 2 + media, 3 + textures
+    if args.force_variant == 6:
+        kinds = 0   # the tolerance mode exists for sphere worlds of the reference's feature set only
     mats = [s.Lambertian(rng.random(3)), s.Metal(rng.random(3), float(rng.choice([0.0, 0.1, 0.7, 1.0]))),
             s.Dielectric((1, 1, 1), float(rng.choice([1.5, 1.33, 1 / 1.5, 2.4]))),
             s.LambertianTexture(rng.random(3), rng.random(3), float(rng.choice([0.2, 0.5, 1.3])))]
@@ -41,7 +43,7 @@ def make_world(rng):
     media = []
     if kinds >= 2:
         media = [s.Isotropic(rng.random(3), float(rng.choice([0.01, 0.3, 2.0])))]
-    big = rng.random() < 0.15
+    big = rng.random() < 0.15 and args.force_variant != 6   # (and for LDS-resident worlds only)
     n = int(rng.integers(1500, 2600)) if big else int(rng.integers(1, 70))
     spread = 30.0 if big else 6.0
     for i in range(n):
