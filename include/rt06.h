@@ -420,6 +420,11 @@ int rt_probe_aabb_regular(int device, size_t n, const float* boxes, const float*
  * right min,max), rays n*6, max_dist n -> out n*8 int32: [regular, uncertain, hit_left, hit_right, swap,
  * exact hit_left, exact hit_right, exact left_dist > right_dist].                                       */
 int rt_probe_boxpair_filtered(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out);
+/* The box pair of the default hot loop (rt_fastdiv.hpp, CERTIFIED FAR PLANES: exact near parameters, far parameters as products with the
+ * rounded reciprocal whose `tmin <= tmax` decisions are certified, exact redo otherwise) next to aabb::intersects (aabb.cuh:26-44) on both
+ * boxes: same layout as above -> out n*8 int32: [regular, could not certify, hit_left, hit_right, left_dist > right_dist,
+ * exact hit_left, exact hit_right, exact left_dist > right_dist].                                                                       */
+int rt_probe_boxpair_certified(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out);
 /* Exhaustive self-test: for each of n_den divisor significands starting at first_den (0 .. 2^23-1) and
  * ALL 2^23 numerator significands, compare the 5-instruction quotient with IEEE n/d bit for bit.
  * num_exp / den_exp are the unbiased exponents given to numerator and divisor.  Returns the number of

@@ -499,6 +499,15 @@ def selftest_fastrcp(device=0):
     return n.value, bad.value, ex.value
 
 
+def probe_boxpair_certified(boxes, rays, max_dist, device=0):
+    """rt_probe_boxpair_certified: the default hot loop's box pair next to the verbatim box tests, (n, 8) int32."""
+    n = len(boxes)
+    out = np.zeros((n, 8), np.int32)
+    check(lib().rt_probe_boxpair_certified(device, n, np.ascontiguousarray(boxes, np.float32), np.ascontiguousarray(rays, np.float32),
+                                           np.ascontiguousarray(max_dist, np.float32), out))
+    return out
+
+
 def probe_boxpair_filtered(boxes, rays, max_dist, device=0):
     n = len(boxes)
     out = np.zeros((n, 8), np.int32)

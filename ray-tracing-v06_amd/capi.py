@@ -71,7 +71,7 @@ SYMBOLS = [
     "rt_renderer_render_async", "rt_renderer_last_kernel_ms", "rt_renderer_kernel_info", "rt_renderer_download", "rt_renderer_shard_floats",
     "rt_renderer_assemble", "rt_renderer_kernel_times", "rt_multi_renderer_create", "rt_multi_renderer_destroy", "rt_multi_renderer_render",
     "rt_multi_renderer_download", "rt_multi_renderer_times", "rt_multi_renderer_gpus", "rt_shard_layout", "rt_shard_pixel_map", "rt_device_info", "rt_scene_set_traversal", "rt_probe_aabb", "rt_probe_sphere", "rt_probe_trace", "rt_probe_scatter",
-    "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_math", "rt_probe_glm", "rt_probe_aabb_misc", "rt_probe_aabb_regular", "rt_probe_boxpair_filtered",
+    "rt_probe_camera", "rt_probe_radiance", "rt_probe_sphere_index", "rt_probe_rng", "rt_probe_math", "rt_probe_glm", "rt_probe_aabb_misc", "rt_probe_aabb_regular", "rt_probe_boxpair_filtered", "rt_probe_boxpair_certified",
     "rt_selftest_fastdiv", "rt_selftest_fastdiv4", "rt_selftest_fastrcp", "rt_device_count", "rt_version", "rt_source_hash", "rt_renderer_pass_info",
 ]
 
@@ -203,6 +203,7 @@ def lib():
     L.rt_probe_aabb_misc.argtypes = [C.c_size_t, f32p, f32p]
     L.rt_probe_aabb_regular.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p, i32p, i32p, f32p]
     L.rt_probe_boxpair_filtered.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p, i32p]
+    L.rt_probe_boxpair_certified.argtypes = [C.c_int, C.c_size_t, f32p, f32p, f32p, i32p]
     L.rt_selftest_fastdiv.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, P(C.c_uint64), u32p]
     L.rt_selftest_fastdiv4.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, P(C.c_uint64), u32p]
     L.rt_selftest_fastrcp.argtypes = [C.c_int32, P(C.c_uint64), P(C.c_uint64), P(C.c_uint32)]

@@ -117,6 +117,36 @@ __device__ __forceinline__ bool slab_near_far_regular(float nx, float ny, float 
     return tmin <= tmax && tmin < ray_max_dist && tmax > 0;
 }
 
+// CERTIFIED FAR PLANES (the default hot loop since round 4): what the traversal needs of the far planes of a box is ONE decision, `tmin <= tmax`
+// (aabb.cuh:41), plus the sign of tmax.  The near parameters stay exact quotients — `tmin` is compared with the sibling's `tmin` (BVH.cu:90), where
+// boxes that share a plane tie exactly and often — but the far ones are products with the rounded reciprocal, t' = RN(n * RN(1/d)) (2 instead of 5
+// instructions per plane), and the decision taken with them is CERTIFIED:
+//     |t' - RN(n/d)| <= 3.02 u |n/d|,  u = 2^-24   (reciprocal, product and quotient round once each; no under- or overflow in the class)
+//  => |min3(t') - min3(q)| <= 3.1 u |min3(t')|
+//  => if |min3(t') - tmin| > 8 u max(|min3(t')| of both boxes), then  tmin <= min3(q)  <=>  tmin <= min3(t').
+// A lane that cannot certify one of its two boxes (a ray that grazes a box edge to within ~2^-21 of the parameter: ~1e-6 of the visits) makes the WAVE
+// redo the far planes of the visit with exact quotients (a wave-uniform, rare branch).  The sign of t' is the sign of the quotient, and zero together
+// with it, so `tmax > 0` needs no margin.  Same decisions as aabb::intersects on every ray of the class by construction; checked against the exact
+// form on adversarial inputs (grazing rays, far parameters within a few ulp of the near ones) by rt_probe_boxpair_certified / tests/test_gpu_parity.py.
+#define RT_FAR_EPS 4.76837158203125e-07f   /* 2^-21 = 8 u */
+__device__ __forceinline__ float slab_near_exact(float nx, float ny, float nz, const Ray& ray, f3 inv_d, f3 inv_lo) {
+    return fmaxf(fmaxf(fast_div_exact4(nx - ray.o.x, ray.d.x, inv_d.x, inv_lo.x), fast_div_exact4(ny - ray.o.y, ray.d.y, inv_d.y, inv_lo.y)),
+                 fast_div_exact4(nz - ray.o.z, ray.d.z, inv_d.z, inv_lo.z));
+}
+__device__ __forceinline__ float slab_far_exact(float fx, float fy, float fz, const Ray& ray, f3 inv_d, f3 inv_lo) {
+    return fminf(fminf(fast_div_exact4(fx - ray.o.x, ray.d.x, inv_d.x, inv_lo.x), fast_div_exact4(fy - ray.o.y, ray.d.y, inv_d.y, inv_lo.y)),
+                 fast_div_exact4(fz - ray.o.z, ray.d.z, inv_d.z, inv_lo.z));
+}
+__device__ __forceinline__ float slab_far_product(float fx, float fy, float fz, const Ray& ray, f3 inv_d) {
+    return fminf(fminf((fx - ray.o.x) * inv_d.x, (fy - ray.o.y) * inv_d.y), (fz - ray.o.z) * inv_d.z);
+}
+// true when the two `tmin <= tmax` decisions taken with the product forms (far_l, far_r) are NOT both certain
+__device__ __forceinline__ bool far_pair_uncertain(float tmin_l, float far_l, float tmin_r, float far_r) {
+    const float gap = fminf(fabsf(far_l - tmin_l), fabsf(far_r - tmin_r));
+    const float scale = fmaxf(fabsf(far_l), fabsf(far_r));
+    return gap <= scale * RT_FAR_EPS;
+}
+
 // TOLERANCE MODE (kernel variant 6, opt-in, NOT bit-exact by construction): the same slab test with the quotients of aabb.cuh:30-31 replaced
 // by products with the correctly rounded reciprocal, t = RN((b - o) * RN(1/d)) — two roundings instead of one, at most ~1 ulp off the true quotient,
 // and still a monotone function of the plane offset for a given ray (so planes that two boxes share still tie exactly).  What BASELINE.json's

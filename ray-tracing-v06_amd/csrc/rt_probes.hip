@@ -467,6 +467,53 @@ __global__ void probe_boxpair_kernel(size_t n, const float* boxes, const float* 
     o[5] = hl; o[6] = hr; o[7] = dl > dr;
 }
 
+// The hot loop's box pair (rt_fastdiv.hpp: CERTIFIED FAR PLANES) next to the verbatim box tests: near parameters as exact quotients, far parameters as
+// products whose `tmin <= tmax` decisions are certified — a lane that cannot certify redoes its far planes exactly (the kernel does that for the whole wave).
+__global__ void probe_boxpair_certified_kernel(size_t n, const float* boxes, const float* rays, const float* maxd, int32_t* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = ld3(rays + 6 * i); r.d = ld3(rays + 6 * i + 3); r.time = 0.0f;
+    const float* b = boxes + 12 * i;
+    bool reg = ray_is_regular(r);
+    for (int k = 0; k < 12; k++) reg = reg && coord_is_regular(b[k]);
+    for (int k = 0; k < 3; k++) reg = reg && b[k] <= b[3 + k] && b[6 + k] <= b[9 + k];
+    int32_t* o = out + 8 * i;
+    for (int k = 0; k < 8; k++) o[k] = 0;
+    o[0] = reg ? 1 : 0;
+    if (!reg) return;
+    const f3 inv_d = mk3(rcp_exact_regular(r.d.x), rcp_exact_regular(r.d.y), rcp_exact_regular(r.d.z));
+    const f3 inv_lo = mk3(rcp_low_word(r.d.x, inv_d.x), rcp_low_word(r.d.y, inv_d.y), rcp_low_word(r.d.z, inv_d.z));
+    // near = the plane the ray enters through (box min where d >= 0), as the kernel's (min, max, min) triples deliver it
+    const bool sx = r.d.x < 0, sy = r.d.y < 0, sz = r.d.z < 0;
+    const float lnx = sx ? b[3] : b[0], lny = sy ? b[4] : b[1], lnz = sz ? b[5] : b[2], lfx = sx ? b[0] : b[3], lfy = sy ? b[1] : b[4], lfz = sz ? b[2] : b[5];
+    const float rnx = sx ? b[9] : b[6], rny = sy ? b[10] : b[7], rnz = sz ? b[11] : b[8], rfx = sx ? b[6] : b[9], rfy = sy ? b[7] : b[10], rfz = sz ? b[8] : b[11];
+    const float tl = slab_near_exact(lnx, lny, lnz, r, inv_d, inv_lo), tr = slab_near_exact(rnx, rny, rnz, r, inv_d, inv_lo);
+    float far_l = slab_far_product(lfx, lfy, lfz, r, inv_d), far_r = slab_far_product(rfx, rfy, rfz, r, inv_d);
+    const bool unc = far_pair_uncertain(tl, far_l, tr, far_r);
+    if (unc) { far_l = slab_far_exact(lfx, lfy, lfz, r, inv_d, inv_lo); far_r = slab_far_exact(rfx, rfy, rfz, r, inv_d, inv_lo); }
+    const bool hl_c = tl <= far_l && tl < maxd[i] && far_l > 0, hr_c = tr <= far_r && tr < maxd[i] && far_r > 0;
+    float dl = RT_MISS_DIST, dr = RT_MISS_DIST;
+    const bool hl = aabb_intersects(ld3(b), ld3(b + 3), r, maxd[i], dl);
+    const bool hr = aabb_intersects(ld3(b + 6), ld3(b + 9), r, maxd[i], dr);
+    o[1] = unc; o[2] = hl_c; o[3] = hr_c; o[4] = (hl_c ? tl : RT_MISS_DIST) > (hr_c ? tr : RT_MISS_DIST);
+    o[5] = hl; o[6] = hr; o[7] = dl > dr;
+}
+
+extern "C" int rt_probe_boxpair_certified(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out) {
+    if (!boxes || !rays || !max_dist || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_boxpair_certified: null argument");
+    if (n == 0) return RT_OK;
+    int rc = select_device(device);
+    if (rc != RT_OK) return rc;
+    DevBuf b, r, m, o;
+    UP(b, boxes, n * 48); UP(r, rays, n * 24); UP(m, max_dist, n * 4);
+    HIP_TRY(o.alloc(n * 32));
+    probe_boxpair_certified_kernel<<<PROBE_GRID(n)>>>(n, b.as<float>(), r.as<float>(), m.as<float>(), o.as<int32_t>());
+    FINISH();
+    DOWN(out, o, n * 32);
+    return RT_OK;
+}
+
 extern "C" int rt_probe_boxpair_filtered(int device, size_t n, const float* boxes, const float* rays, const float* max_dist, int32_t* out) {
     if (!boxes || !rays || !max_dist || !out) return rt_fail(RT_ERR_INVALID, "rt_probe_boxpair_filtered: null argument");
     if (n == 0) return RT_OK;

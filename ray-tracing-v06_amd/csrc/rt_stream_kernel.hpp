@@ -352,10 +352,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
                         const uint32_t left_idx = nd.left, right_idx = nd.right;
                         float tl, tr;
-                        const bool hl = TOL ? slab_near_far_tolerant(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl)
-                                            : slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
-                        const bool hr = TOL ? slab_near_far_tolerant(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr)
-                                            : slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
+                        bool hl, hr;
+                        if (TOL) {
+                            hl = slab_near_far_tolerant(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl);
+                            hr = slab_near_far_tolerant(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr);
+                        } else {
+#ifdef RT_FAR_ALL_EXACT   /* A/B switch of round 4: all twelve plane parameters as exact quotients (the hot loop of rounds 1-3) */
+                            hl = slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
+                            hr = slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
+#else
+                            // near parameters: exact quotients (tl, tr are compared with each other and with rec.distance); far parameters: products,
+                            // with the `tmin <= tmax` decisions certified (rt_fastdiv.hpp: CERTIFIED FAR PLANES) — or, rarely and for the whole wave,
+                            // redone exactly from a second read of the node
+                            tl = slab_near_exact(nd.lnx, nd.lny, nd.lnz, ray, inv_d, inv_lo);
+                            tr = slab_near_exact(nd.rnx, nd.rny, nd.rnz, ray, inv_d, inv_lo);
+                            float far_l = slab_far_product(nd.lfx, nd.lfy, nd.lfz, ray, inv_d);
+                            float far_r = slab_far_product(nd.rfx, nd.rfy, nd.rfz, ray, inv_d);
+                            if (__ballot(far_pair_uncertain(tl, far_l, tr, far_r)) != 0ull) {
+                                asm volatile("" ::: "memory");   // (a second read of the node: the common path need not keep six plane offsets alive)
+                                const WideNodeData n2 = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
+                                far_l = slab_far_exact(n2.lfx, n2.lfy, n2.lfz, ray, inv_d, inv_lo);
+                                far_r = slab_far_exact(n2.rfx, n2.rfy, n2.rfz, ray, inv_d, inv_lo);
+                            }
+                            hl = tl <= far_l && tl < rec_t && far_l > 0;
+                            hr = tr <= far_r && tr < rec_t && far_r > 0;
+#endif
+                        }
                         // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
                         // (missed box = _MISS_DIST) is "right hit and (left missed or tl > tr)".

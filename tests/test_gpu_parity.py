@@ -555,6 +555,58 @@ def test_filtered_box_pair_predicates_are_sound(p):
     assert out[sure, 2].mean() > 0.02 and out[sure, 4].mean() > 0.005
 
 
+def test_certified_far_planes_take_the_exact_decisions(p):
+    """The default hot loop's box pair (rt_fastdiv.hpp, CERTIFIED FAR PLANES): near parameters exact, far parameters products with the rounded
+    reciprocal, `tmin <= tmax` certified or redone exactly.  Its three decisions must equal aabb::intersects' on EVERY regular case — random pairs,
+    sibling boxes that share faces, rays aimed exactly at corners and edge points of a box (tmin == tmax up to rounding: the cases the certification
+    exists for), flat boxes (tmin == tmax on an axis), rays starting on a face, rec_t on the entry distance."""
+    rng = np.random.default_rng(29)
+    n = 1 << 21
+    lo = ((rng.random((n, 3), dtype=np.float32) * 2 - 1) * 12).astype(np.float32)
+    ext = (rng.random((n, 3), dtype=np.float32) * 3 + 0.01).astype(np.float32)
+    flat = rng.random((n, 3)) < 0.03
+    ext[flat] = 0.0                                   # zero-thickness boxes on some axes: near == far plane there
+    left = np.concatenate([lo, lo + ext], axis=1)
+    shift = np.where(rng.random((n, 3)) < 0.5, 0.0, rng.random((n, 3)) * 2 - 1).astype(np.float32)
+    rlo = (lo + shift * ext).astype(np.float32)
+    rext = np.where(rng.random((n, 3)) < 0.5, ext, (rng.random((n, 3), dtype=np.float32) * 3 + 0.01)).astype(np.float32)
+    right = np.concatenate([rlo, rlo + rext], axis=1)
+    boxes = np.ascontiguousarray(np.concatenate([left, right], axis=1), dtype=np.float32)
+    rays = random_rays(rng, n, with_time=False)
+    q = n // 4
+    # a quarter: aimed exactly at a corner of the left box; another quarter: at a point of an EDGE (two coordinates on planes, one inside)
+    corner = np.where(rng.random((q, 3)) < 0.5, left[:q, 0:3], left[:q, 3:6]).astype(np.float32)
+    rays[:q, 3:6] = (corner - rays[:q, 0:3]) * (rng.random((q, 1), dtype=np.float32) + 0.5)
+    edge = np.where(rng.random((q, 3)) < 0.5, right[q:2 * q, 0:3], right[q:2 * q, 3:6]).astype(np.float32)
+    free = rng.integers(0, 3, q)
+    t = rng.random(q, dtype=np.float32)
+    edge[np.arange(q), free] = (right[q:2 * q, 0:3][np.arange(q), free] * (1 - t) + right[q:2 * q, 3:6][np.arange(q), free] * t).astype(np.float32)
+    rays[q:2 * q, 3:6] = (edge - rays[q:2 * q, 0:3]) * (rng.random((q, 1), dtype=np.float32) * 3 + 0.25)
+    # an eighth: the origin ON a face plane of the left box (a zero plane offset: t == 0 exactly)
+    k = np.arange(2 * q, 2 * q + n // 8)
+    ax = rng.integers(0, 3, len(k))
+    rays[k, ax] = np.where(rng.random(len(k)) < 0.5, left[k, ax], left[k, 3 + ax])
+    maxd = np.where(rng.random(n) < 0.5, np.float32(3.402823466e38), rng.random(n, dtype=np.float32) * 30).astype(np.float32)
+    hit, dist = p.api.probe_aabb(np.ascontiguousarray(boxes[:, 0:6]), rays, np.full(n, 3.402823466e38, np.float32))
+    kk = np.where(hit[: n // 8] == 1)[0]
+    maxd[kk] = dist[kk]                                # rec_t exactly on the left box's entry distance
+    out = p.api.probe_boxpair_certified(boxes, rays, maxd)
+    reg = out[:, 0] == 1
+    assert reg.mean() > 0.9
+    assert np.array_equal(out[reg, 2], out[reg, 5]), f"hit_left differs in {(out[reg, 2] != out[reg, 5]).sum()} cases"
+    assert np.array_equal(out[reg, 3], out[reg, 6]), f"hit_right differs in {(out[reg, 3] != out[reg, 6]).sum()} cases"
+    assert np.array_equal(out[reg, 4], out[reg, 7]), f"near/far order differs in {(out[reg, 4] != out[reg, 7]).sum()} cases"
+    unc = out[reg, 1].mean()
+    tail = np.zeros(n, bool)
+    tail[3 * q + n // 8:] = True                       # the random tail of the set, boxes of non-zero thickness: what a traversal sees
+    tail &= reg & ~flat.any(axis=1) & (rext > 0).all(axis=1)
+    plain = out[tail, 1].mean()
+    print(f"certified far planes: exact redo on {unc:.2e} of {reg.sum()} adversarial visits, {plain:.2e} of the random ones")
+    assert unc > 1e-4        # the adversarial set does reach the fallback (corner / edge rays), so the test covers it
+    assert plain < 1e-4      # random visits almost never do
+    assert out[reg, 2].mean() > 0.02 and out[reg, 4].mean() > 0.005
+
+
 # ------------------------------------------------------------------------------------------------
 # world shapes and materials beyond the prefab scenes
 # ------------------------------------------------------------------------------------------------
