@@ -147,6 +147,21 @@ __device__ __forceinline__ bool far_pair_uncertain(float tmin_l, float far_l, fl
     return gap <= scale * RT_FAR_EPS;
 }
 
+// The root box of a trace (BVH.cu:59-60) decides one thing — is the world entered at all, against a fresh rec.distance = _MISS_DIST — so ALL six of its
+// plane parameters can be products: `tmin <= tmax` is certified as above (both sides are approximate now: twice the margin), `tmin < _MISS_DIST` holds
+// for every parameter of the class, `tmax > 0` is sign-exact; a lane that cannot certify (a ray that grazes the world's bounds) takes the exact test.
+__device__ __forceinline__ bool root_box_hit_certified(f3 box_min, f3 box_max, const Ray& ray, f3 inv_d) {
+    const float ax = (box_min.x - ray.o.x) * inv_d.x, ay = (box_min.y - ray.o.y) * inv_d.y, az = (box_min.z - ray.o.z) * inv_d.z;
+    const float bx = (box_max.x - ray.o.x) * inv_d.x, by = (box_max.y - ray.o.y) * inv_d.y, bz = (box_max.z - ray.o.z) * inv_d.z;
+    const float tmin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float tmax = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    if (fabsf(tmax - tmin) <= fmaxf(fabsf(tmin), fabsf(tmax)) * (2.0f * RT_FAR_EPS)) {   // rare, per lane
+        float d;
+        return aabb_intersects_regular(box_min, box_max, ray, inv_d, RT_MISS_DIST, d);
+    }
+    return tmin <= tmax && tmax > 0;
+}
+
 // TOLERANCE MODE (kernel variant 6, opt-in, NOT bit-exact by construction): the same slab test with the quotients of aabb.cuh:30-31 replaced
 // by products with the correctly rounded reciprocal, t = RN((b - o) * RN(1/d)) — two roundings instead of one, at most ~1 ulp off the true quotient,
 // and still a monotone function of the plane offset for a given ray (so planes that two boxes share still tie exactly).  What BASELINE.json's

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
         bool hit_root_;                                                    \
         if (WORLD == RT_WORLD_NODE_TREE) hit_root_ = true;                 \
         else if (EXACT || !regular) hit_root_ = aabb_intersects(root_min, root_max, ray, rec_t, d_root_);         \
-        else hit_root_ = aabb_intersects_regular(root_min, root_max, ray, inv_d, rec_t, d_root_);                 \
+        else hit_root_ = root_box_hit_certified(root_min, root_max, ray, inv_d);   /* rec_t is _MISS_DIST here */  \
         if (hit_root_) {                                                   \
             cur = p.scene.root_ref;                                        \
             if (FAST_BVH && !regular && cur < K_LEAF) cur |= K_IRR; \
@@ -357,10 +357,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                             hl = slab_near_far_tolerant(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl);
                             hr = slab_near_far_tolerant(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr);
                         } else {
-#ifdef RT_FAR_ALL_EXACT   /* A/B switch of round 4: all twelve plane parameters as exact quotients (the hot loop of rounds 1-3) */
-                            hl = slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
-                            hr = slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
-#else
                             // near parameters: exact quotients (tl, tr are compared with each other and with rec.distance); far parameters: products,
                             // with the `tmin <= tmax` decisions certified (rt_fastdiv.hpp: CERTIFIED FAR PLANES) — or, rarely and for the whole wave,
                             // redone exactly from a second read of the node
@@ -376,7 +372,6 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                             }
                             hl = tl <= far_l && tl < rec_t && far_l > 0;
                             hr = tr <= far_r && tr < rec_t && far_r > 0;
-#endif
                         }
                         // BVH.cu:87-96, see the generic loop below: with both boxes hit the far child is pushed and the near
                         // one continues; with one hit it continues; with none the stack is popped.  `left_dist > right_dist`
