@@ -347,6 +347,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                 // inner_keep >= 1 (host); once the queue is dry the wave only drains its last paths: no reason to leave early.  The threshold is
                 // wave-uniform; readfirstlane tells the compiler so (a scalar compare and branch instead of a vector compare and an exec-mask loop exit)
                 const uint32_t keep_now = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pool_dry ? 1u : p.inner_keep));
+                // Certified far planes (rt_fastdiv.hpp) pay where boxes have thickness.  The box of an axis-aligned quad is 1e-4 thick: the near and far
+                // parameters of a ray that hits it agree to ~2e-7, inside the certificate's margin, so nearly every hit box would take the exact redo
+                // (measured: Cornell box -6 %, Book-2 final scene -5 %).  Worlds with quads therefore keep the twelve exact quotients; the reference's
+                // feature set has no quads (EXT == 0: decided at compile time), the EXT kernels decide per world (wave-uniform).
+                const bool far_certified = EXT == 0 || p.scene.n_quads == 0u;
                 do {
                     if (at_inner) {
                         const WideNodeData nd = fetch_wide_node<BIG>(nodes, lds, p.scene.n_top, cur, kx, ky, kz);
@@ -356,6 +361,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void render_kernel_stream(Strea
                         if (TOL) {
                             hl = slab_near_far_tolerant(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, rec_t, tl);
                             hr = slab_near_far_tolerant(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, rec_t, tr);
+                        } else if (!far_certified) {   // a world with quads: all twelve parameters as exact quotients
+                            hl = slab_near_far_regular(nd.lnx, nd.lny, nd.lnz, nd.lfx, nd.lfy, nd.lfz, ray, inv_d, inv_lo, rec_t, tl);
+                            hr = slab_near_far_regular(nd.rnx, nd.rny, nd.rnz, nd.rfx, nd.rfy, nd.rfz, ray, inv_d, inv_lo, rec_t, tr);
                         } else {
                             // near parameters: exact quotients (tl, tr are compared with each other and with rec.distance); far parameters: products,
                             // with the `tmin <= tmax` decisions certified (rt_fastdiv.hpp: CERTIFIED FAR PLANES) — or, rarely and for the whole wave,
