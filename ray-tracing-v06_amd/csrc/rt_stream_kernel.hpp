@@ -44,8 +44,8 @@
 #define RT_WORLD_BVH_QUEUE 3     // internal WORLD mode of render_kernel_stream: an RT_WORLD_BVH world walked by each lane on its own — the distance-sorted queue (RT_TRAVERSAL_QUEUE) or the 4-wide walk (RT_TRAVERSAL_WIDE4)
 #define RT_CHUNK_MAX 768u        // sample indices a wave pulls per atomic (the host shrinks it for small frames / shards); 768 measured 0.35 ms ahead of 1024 and of 512 on config 2
 // scheduling thresholds (lanes of 64); overridable per renderer for tuning (RT06_TUNE=keep,shade,leaf)
-#define RT_INNER_KEEP 40         // keep iterating inner-node steps while at least this many lanes want one
-#define RT_SHADE_MIN 56          // run the shade/regenerate phase once this many lanes wait for it
+#define RT_INNER_KEEP 36         // keep iterating inner-node steps while at least this many lanes want one (round 4, with the cheaper hot step: 36 / 52 / 4 is 0.3-1.2 % ahead of 40 / 56 / 4 on all four workloads)
+#define RT_SHADE_MIN 52          // run the shade/regenerate phase once this many lanes wait for it
 #define RT_LEAF_MIN 4            // run the leaf phase once this many lanes sit at a leaf (or nobody is at an inner node)
 
 // A primary-ray record is read exactly once: a non-temporal load, so that this 23 GB stream does not push the partially written lines of
