@@ -36,7 +36,7 @@ import __graft_entry__ as G  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def BIT_EXACT(resolved_variant):
+def is_bit_exact_variant(resolved_variant):
     """The streaming kernels (variants 2-5; 0 resolves to one of them) promise the oracle's bits.  Variant 1 (wave-per-pixel baseline: another
     summation order) and variant 6 (opt-in tolerance mode: products with the rounded reciprocal in the box tests) are held to north_star's
     tolerance |delta| < 1e-3 instead; whether their frame was bit-identical anyway is reported."""
@@ -247,7 +247,7 @@ def sparse_leg(args, frame_rgba, tolerance_only=False):
            "max_abs_delta": float(np.nanmax(np.abs(got - exp))), "oracle_seconds": round(time.perf_counter() - t, 2),
            "sample": "pixels of the last timed frame vs O.render_pixels at the full sample count, same seed"}
     # the streaming kernels' contract (variants 2-5; 0 resolves to one of them) is the oracle's bits; the wave-per-pixel baseline (variant 1:
-    # another summation order) and the opt-in tolerance mode (variant 6) are held to the 1e-3 tolerance (BIT_EXACT above)
+    # another summation order) and the opt-in tolerance mode (variant 6) are held to the 1e-3 tolerance (is_bit_exact_variant above)
     if not res["bit_identical"] and (not tolerance_only or not (res["max_abs_delta"] < 1e-3)):
         raise SystemExit(f"full-spp sparse parity failed: {res}")
     return res
@@ -422,7 +422,7 @@ def main():
                 img = rr.DownloadRenderbuffer()
                 rr.close()
                 return img
-            base, counts, parity = cpu_leg(args, pkg, scene, cam, None if args.no_parity else gpu_image, bit_exact_contract=BIT_EXACT(kinfo["variant"]))
+            base, counts, parity = cpu_leg(args, pkg, scene, cam, None if args.no_parity else gpu_image, bit_exact_contract=is_bit_exact_variant(kinfo["variant"]))
         value = total_samples * args.steps / elapsed / 1e6
         out = {
             "metric": "Msamples/sec (WxHxspp) on Book-1 final scene" if args.workload == "book1_final" else f"Msamples/sec (WxHxspp) on {args.workload}",
@@ -521,7 +521,7 @@ def main():
             if parity is not None:
                 out["parity"] = parity
             if world_size == 1 and args.sparse_parity > 0 and not args.no_parity and args.steps > 0:
-                out["parity_timed_frame"] = sparse_leg(args, images[(frame[0] - 1) % depth].cpu().numpy(), tolerance_only=not BIT_EXACT(kinfo["variant"]))
+                out["parity_timed_frame"] = sparse_leg(args, images[(frame[0] - 1) % depth].cpu().numpy(), tolerance_only=not is_bit_exact_variant(kinfo["variant"]))
         if args.verify_assembly and world_size > 1:
             solo = pkg.Renderer.MakeRenderer(W, H, spp, args.depth, cam, world, seed=args.seed, device=local_rank, variant=args.variant)
             solo.Render()
