@@ -68,6 +68,21 @@ def test_every_roofline_fraction_of_the_headline_line_is_a_fraction():
     assert d["parity"]["bit_identical"] is True and d["parity_timed_frame"]["bit_identical"] is True
 
 
+def test_tolerance_mode_line_names_its_variant_and_its_own_counters():
+    """`bench.py --variant 6` (opt-in tolerance mode): the line says which kernel variant ran, prices the roofline with the counter summary taken WITH that
+    variant (profiles/rNN_bench_v6_pmc_summary.csv, `# config: ... variant=6`), and its parity legs are held to 1e-3 and report bit-identity"""
+    d = _bench("--variant", "6", "--spp", "40", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--sparse-parity", "8")
+    assert d["config"]["kernel_variant"] == 6
+    r = d["roofline"]
+    assert r["counters_source"].endswith("bench_v6_pmc_summary.csv") and 0.0 < r["frac"] <= 1.0
+    assert d["parity"]["max_abs_delta"] < 1e-3 and d["parity"]["tolerance"] == 1e-3 and isinstance(d["parity"]["bit_identical"], bool)
+    assert d["parity_timed_frame"]["max_abs_delta"] < 1e-3
+    e = _bench("--spp", "40", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0", "--no-parity")
+    assert e["config"]["kernel_variant"] == 0 and e["roofline"]["counters_source"].endswith("bench_pmc_summary.csv")
+    # fewer vector instructions per launch than the default kernel's summary: the products replace the near quotients too
+    assert r["wave_instructions_per_launch"] < e["roofline"]["wave_instructions_per_launch"]
+
+
 def test_multi_pass_workload_line(monkeypatch):
     """three passes per step: the per-kernel times are sums over the passes and the counters are found by workload + size + depth"""
     d = _bench("--workload", "cornell_box", "--spp", "30", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", env={"RT06_PASS_SPP": "10"})
