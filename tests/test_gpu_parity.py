@@ -620,6 +620,21 @@ def _render_both(p, scene, cam, W, H, spp, depth=50, variant=0):
     return img, ref
 
 
+@pytest.mark.parametrize("W,H,spp,depth", [(1, 1, 1, 1), (1, 1, 7, 50), (1, 9, 3, 50), (9, 1, 3, 50), (8, 8, 1, 2), (7, 7, 65, 50), (17, 1, 129, 4)])
+def test_smallest_frames_render_bit_exact(p, W, H, spp, depth):
+    """the smallest inputs the boundary accepts — one pixel, one row, one column, exactly one 8x8 tile, less than a tile — on the streaming kernel
+    (a pass of 1 .. 1105 sample indices, mostly padding) and on the baseline kernel: the oracle's frame"""
+    scene = p.Scene.book1_final(1984)
+    cam = p.DefocusBlurCamera((13, 2, 3), (0, 0, 0), (0, 1, 0), 20.0, W / H, 0.1, 10.0)
+    for variant in (0, 1):
+        img, ref = _render_both(p, scene, cam, W, H, spp, depth, variant=variant)
+        assert img.shape == (H, W, 4)
+        if variant == 0:
+            assert bits_equal(img, ref), mismatch_report(img, ref)
+        else:   # (the baseline kernel sums a pixel's samples in another order)
+            assert np.nanmax(np.abs(img - ref)) <= 1e-5
+
+
 @pytest.mark.parametrize("n_spheres", [1, 2, 3])
 def test_tiny_bvh_worlds_render_bit_exact(p, n_spheres):
     """A BVH whose root is a leaf (one sphere) or has leaf children only — the streaming kernel's degenerate trees."""
